@@ -1,0 +1,155 @@
+/* rt355.h — C-ABI of the MI355X-native per-pixel ray-tracing path.
+ *
+ * This library replaces what the reference's `src/gpu` module does for
+ * `App::render_scene` (src/app.rs:208-254): the wgpu bind group + full-screen
+ * draw whose fragment shader is the ray tracer (src/shaders/frag.hlsl:48-66)
+ * become one hand-written HIP kernel for gfx950.  Each entry point below names
+ * the reference call it stands in for.  The wire formats of the blobs are in
+ * rt355_layout.h.
+ *
+ * Conventions: every function returns 0 on success or a
+ * negative rt_status; no C++ exception crosses the boundary; every pointer is
+ * borrowed for the duration of the call only (inputs are copied before the
+ * call returns); a context is driven from one render thread, except
+ * rt_set_random which may be called concurrently from another thread (the
+ * reference's RandomTexture thread, src/gpu/random_texture.rs:56-61).
+ * There is no CPU fallback: rt_create fails with RT_ERR_NO_DEVICE when no
+ * gfx950 device is usable.
+ */
+#ifndef RT355_H
+#define RT355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rt355_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT355_ABI_VERSION 1
+#define RT355_API __attribute__((visibility("default")))
+
+typedef enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID_ARGUMENT = -1, /* NULL / zero size / size mismatch                      */
+  RT_ERR_NO_DEVICE = -2,        /* no HIP device, or device id out of range              */
+  RT_ERR_NOT_READY = -3,        /* render before skybox / random / scene / size were set */
+  RT_ERR_DEVICE = -4,           /* a HIP call failed; text in rt_last_error              */
+  RT_ERR_OUT_OF_MEMORY = -5
+} rt_status;
+
+typedef struct rt_context rt_context;
+
+/* Accumulation modes (App. B D7). */
+enum {
+  RT_ACCUM_SRGB8 = 0, /* reference-exact: history is the stored Rgba8UnormSrgb texel */
+  RT_ACCUM_FLOAT32 = 1 /* linear float history (quality mode, not in the reference)  */
+};
+
+/* Optional per-pixel outputs, OR-ed into rt_set_outputs. */
+enum {
+  RT_OUT_RGBA8 = 1,    /* always produced (it is also the sRGB8 history)                    */
+  RT_OUT_RGBF32 = 2,   /* linear float value before the sRGB store (parity / HDR consumers) */
+  RT_OUT_SEGMENTS = 4, /* executed iterations of frag.hlsl:36-43 per pixel                  */
+  RT_OUT_HITS = 8      /* object_index per iteration (reflection_limit ints per pixel)      */
+};
+
+typedef struct rt_stats {
+  uint64_t frames;            /* rt_render calls completed                                  */
+  uint64_t last_segments;     /* ray segments (bounce-loop iterations) of the last frame    */
+  uint64_t last_rough_hits;   /* segments of the last frame that drew random() (rough hit)  */
+  uint64_t last_pixels;       /* pixels this context rendered in the last frame             */
+  float last_kernel_ms;       /* HIP-event time of the last frame's render kernel           */
+  uint32_t width, height;     /* full frame                                                 */
+  uint32_t local_rows;        /* rows owned by this context under the current partition     */
+  uint32_t object_count, sphere_count, plane_count;
+} rt_stats;
+
+/* Device-side view of the context's buffers, for zero-copy consumers (RCCL gather,
+ * interop).  All pointers are device addresses on the context's GPU and stay valid
+ * until the next rt_resize / rt_set_partition / rt_set_outputs / rt_destroy. */
+typedef struct rt_device_buffers {
+  void *rgba8;          /* local_rows x width x 4 B, sRGB-encoded, alpha 255 */
+  void *rgbf32;         /* local_rows x width x 3 floats, or NULL            */
+  void *segments;       /* local_rows x width x u32, or NULL                 */
+  void *hits;           /* local_rows x width x reflection_limit x i32, or NULL */
+  void *stream;         /* hipStream_t all of the context's work is ordered on */
+  uint32_t width, local_rows;
+} rt_device_buffers;
+
+/* `Initial::gpu_setup` (src/app.rs:64-104): bind one GPU.  One context per process
+ * and GPU; multi-GPU runs create one context per rank (see rt_set_partition). */
+RT355_API int rt_create(int device_id, rt_context **out_ctx);
+RT355_API int rt_destroy(rt_context *ctx);
+RT355_API uint32_t rt_abi_version(void);
+
+/* `Connection::load_hdri` (src/gpu/connection.rs:176-215): RGBA32F equirectangular
+ * panorama, tightly packed rows, row 0 = top.  Sampled nearest / clamp-to-edge
+ * (connection.rs:164-174). */
+RT355_API int rt_set_skybox(rt_context *ctx, uint32_t width, uint32_t height, const float *rgba32f);
+
+/* `RandomTexture::write` (src/gpu/random_texture.rs:78-101): R32F noise texture the
+ * shader's random() indexes (src/shaders/random.hlsl:4-11).  Thread-safe against
+ * every other call; a frame sees either the old or the new texture, never a mix. */
+RT355_API int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float *r32f);
+
+/* The dirty branch of `Connection::update_buffers` (connection.rs:373-385): objects in
+ * the 112-byte wire format with an EXPLICIT count (the reference derives 80 from the
+ * buffer size, inputs.hlsl:77-80 — pass 80 zero-padded slots for reference-exact
+ * behaviour), lights (accepted, never read — as in the shader), Config blob.
+ * Config.width/height must equal the size given to rt_resize. */
+RT355_API int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, const void *lights,
+                 uint32_t light_count, const void *config112);
+
+/* `RenderTarget::new/resize` (src/gpu/render_target.rs:39-48,72-75): (re)allocate the
+ * output and BOTH history buffers (the reference forgets the history). */
+RT355_API int rt_resize(rt_context *ctx, uint32_t width, uint32_t height);
+
+/* Tile partition for multi-GPU frames (no reference counterpart): the frame is cut
+ * into strips of `strip_rows` rows dealt round-robin over `world` contexts; this
+ * context renders the strips with index % world == rank into compact local buffers
+ * (local row order = ascending global row).  rank 0 / world 1 = the whole frame. */
+RT355_API int rt_set_partition(rt_context *ctx, uint32_t rank, uint32_t world, uint32_t strip_rows);
+
+RT355_API int rt_set_accum_mode(rt_context *ctx, int mode);
+RT355_API int rt_set_outputs(rt_context *ctx, uint32_t out_flags);
+
+/* The render pass + history copy + submit of `App::render_scene` (app.rs:219-250) and
+ * the FrameData upload of update_buffers (connection.rs:390-409).  Jitter and
+ * progressive_count are supplied by the caller (the reference draws them itself,
+ * which makes its output irreproducible).  Asynchronous: returns after the launch. */
+RT355_API int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progressive_count);
+RT355_API int rt_render_frame(rt_context *ctx, const void *framedata16); /* same, FrameData blob */
+RT355_API int rt_sync(rt_context *ctx);
+
+/* `RenderTarget::update` hands the wgpu view to egui (render_target.rs:50-70); here the
+ * caller reads the pixels back (or uses rt_get_device_buffers).  Local rows only. */
+RT355_API int rt_read_rgba8(rt_context *ctx, void *dst, size_t bytes);
+RT355_API int rt_read_rgbf32(rt_context *ctx, float *dst, size_t bytes);
+RT355_API int rt_read_segments(rt_context *ctx, uint32_t *dst, size_t bytes);
+RT355_API int rt_read_hits(rt_context *ctx, int32_t *dst, size_t bytes);
+/* Overwrite the sRGB8 history (e.g. to resume an accumulation); local rows. */
+RT355_API int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes);
+
+RT355_API int rt_get_device_buffers(rt_context *ctx, rt_device_buffers *out);
+RT355_API int rt_get_stats(rt_context *ctx, rt_stats *out);
+/* Text of the most recent error on this context (valid until the next call on it). */
+RT355_API const char *rt_last_error(rt_context *ctx);
+
+/* Kernel variant: 0 = sphere records staged in LDS (default), 1 = sphere records through the
+ * scalar cache.  Results are identical; the benchmark compares their speed. */
+RT355_API int rt_set_variant(rt_context *ctx, int variant);
+
+/* Device self-test hooks used by the parity tests: evaluate the device build of the
+ * specified math function over n host values (op: 0 sin 1 cos 2 tan 3 asin 4 log2
+ * 5 exp2 6 sqrt; binary op: 0 atan2(a,b) 1 pow(a,b) 2 a/b). */
+RT355_API int rt_selftest_math_unary(rt_context *ctx, int op, const float *x, float *y, size_t n);
+RT355_API int rt_selftest_math_binary(rt_context *ctx, int op, const float *a, const float *b, float *y, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT355_H */

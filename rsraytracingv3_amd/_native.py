@@ -1,0 +1,88 @@
+"""ctypes binding of ``librt355.so`` (C-ABI in ``include/rt355.h``).
+
+There is no fallback: if the shared library is missing or no gfx950 device can be
+opened, every entry point raises.  The library is built in-tree by
+``__graft_entry__.build()`` / ``make -C rsraytracingv3_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt355.so")
+
+RT_OK = 0
+RT_ACCUM_SRGB8, RT_ACCUM_FLOAT32 = 0, 1
+RT_OUT_RGBA8, RT_OUT_RGBF32, RT_OUT_SEGMENTS, RT_OUT_HITS = 1, 2, 4, 8
+
+STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_NOT_READY",
+                -4: "RT_ERR_DEVICE", -5: "RT_ERR_OUT_OF_MEMORY"}
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, where: str, text: str = ""):
+        self.code = code
+        super().__init__("%s: %s%s" % (where, STATUS_NAMES.get(code, str(code)), (" — " + text) if text else ""))
+
+
+class RtStats(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("last_segments", C.c_uint64), ("last_rough_hits", C.c_uint64),
+                ("last_pixels", C.c_uint64), ("last_kernel_ms", C.c_float), ("width", C.c_uint32),
+                ("height", C.c_uint32), ("local_rows", C.c_uint32), ("object_count", C.c_uint32),
+                ("sphere_count", C.c_uint32), ("plane_count", C.c_uint32)]
+
+
+class RtDeviceBuffers(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("rgbf32", C.c_void_p), ("segments", C.c_void_p), ("hits", C.c_void_p),
+                ("stream", C.c_void_p), ("width", C.c_uint32), ("local_rows", C.c_uint32)]
+
+
+# name -> (restype, argtypes); every symbol include/rt355.h declares
+_vp, _u32, _i, _f, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_size_t
+SIGNATURES = {
+    "rt_abi_version": (_u32, []),
+    "rt_create": (_i, [_i, C.POINTER(_vp)]),
+    "rt_destroy": (_i, [_vp]),
+    "rt_set_skybox": (_i, [_vp, _u32, _u32, _vp]),
+    "rt_set_random": (_i, [_vp, _u32, _u32, _vp]),
+    "rt_set_scene": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "rt_resize": (_i, [_vp, _u32, _u32]),
+    "rt_set_partition": (_i, [_vp, _u32, _u32, _u32]),
+    "rt_set_accum_mode": (_i, [_vp, _i]),
+    "rt_set_outputs": (_i, [_vp, _u32]),
+    "rt_set_variant": (_i, [_vp, _i]),
+    "rt_render": (_i, [_vp, _f, _f, _u32]),
+    "rt_render_frame": (_i, [_vp, _vp]),
+    "rt_sync": (_i, [_vp]),
+    "rt_read_rgba8": (_i, [_vp, _vp, _sz]),
+    "rt_read_rgbf32": (_i, [_vp, _vp, _sz]),
+    "rt_read_segments": (_i, [_vp, _vp, _sz]),
+    "rt_read_hits": (_i, [_vp, _vp, _sz]),
+    "rt_write_history_rgba8": (_i, [_vp, _vp, _sz]),
+    "rt_get_device_buffers": (_i, [_vp, C.POINTER(RtDeviceBuffers)]),
+    "rt_get_stats": (_i, [_vp, C.POINTER(RtStats)]),
+    "rt_last_error": (C.c_char_p, [_vp]),
+    "rt_selftest_math_unary": (_i, [_vp, _i, _vp, _vp, _sz]),
+    "rt_selftest_math_binary": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),
+}
+
+_lib = None
+
+
+def load():
+    """Load ``librt355.so``; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "rt355: %s not found — the HIP extension is not built.  Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C rsraytracingv3_amd/csrc`. "
+                "There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,69 @@
+// rt_device.h — data shared between the C-ABI shim (host) and the gfx950 kernels.
+//
+// HBM layout of one context (DESIGN.md "Data layout"):
+//   compiled scene   one allocation of float4 records, re-laid out from the 112-byte AoS wire
+//                    objects (objects.rs:202-214) into what the kernel reads:
+//                      sph[n_sph]      {cx, cy, cz, r*r}        scanned by every ray segment,
+//                                                               staged into LDS per workgroup
+//                      sph_obj[n_sph]  original object index    (ascending; tie-break D10)
+//                      pl_a[n_pl]      {cx, cy, cz, half_size}
+//                      pl_b[n_pl]      {nx, ny, nz, bits(object index)}
+//                      mat0[n_obj]     {2*colour.rgb, roughness}         fetched for the winner only
+//                      mat1[n_obj]     {emission*strength .rgb, 1/(phong_alpha+1)}
+//   skybox           RGBA32F, row-major, row 0 = top (connection.rs:187-212)
+//   random           R32F row-major (random_texture.rs:30-39), double buffered
+//   rgba8            local_rows x W x 4 B: the Rgba8UnormSrgb target AND its own history
+//   rgbf32 / hist    local_rows x W x 3 floats (optional output / float accumulation)
+#pragma once
+
+#include <cstdint>
+
+#include "rt_math.h"
+
+namespace rt355 {
+
+struct DeviceScene {
+  const float4 *sph;
+  const int *sph_obj;
+  const float4 *pl_a;
+  const float4 *pl_b;
+  const float4 *mat0;
+  const float4 *mat1;
+  uint32_t n_sph, n_pl, n_obj;
+};
+
+struct FrameParams {
+  uint32_t width, height;      // full frame (Config.width/height, scene.rs:267-268)
+  uint32_t reflection_limit;   // Config.reflection_limit
+  uint32_t progressive_count;  // FrameData (connection.rs:13-16)
+  float jitter_x, jitter_y;
+  float opacity, keep;         // 1/(progressive_count+1) and 1 - that (frag.hlsl:61-62)
+  // pixel-independent part of create_ray (ray.hlsl:16-29), evaluated on the host
+  f3 cam_pos, cam_right, cam_neg_up, top_left;
+  float vp_width, vp_height;
+  const float4 *hdri;
+  uint32_t hdri_w, hdri_h;
+  const float *rnd;
+  uint32_t rnd_w, rnd_h;
+  // row-strip partition (rt_set_partition)
+  uint32_t rank, world, strip_rows, local_rows;
+  // outputs
+  uint32_t *rgba8;
+  float *rgbf32;    // may be null
+  float *hist_f32;  // RT_ACCUM_FLOAT32 history, else null
+  uint32_t *segments;  // may be null
+  int32_t *hits;       // may be null
+  unsigned long long *counters;  // [0] segments, [1] rough hits
+  const float *srgb_lut;         // 256 decoded values
+  int accum_mode;
+};
+
+// kernels (rt_kernels.hip)
+struct LaunchConfig {
+  int variant;  // 0 = tile kernel, LDS-staged geometry; 1 = tile kernel, scalar-cache geometry
+};
+int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream);
+int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);
+int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream);
+
+}  // namespace rt355

@@ -1,0 +1,592 @@
+// rt_shim.hip — implementation of the rt355 C-ABI (include/rt355.h) on one gfx950 device.
+//
+// Stands in for src/gpu/{connection,render_target,random_texture}.rs of the reference: it
+// owns the device copies of the bind-group resources (connection.rs:314-347), re-lays the
+// wire-format scene out for the kernel, evaluates the per-frame uniform maths on the host
+// with the same specified float32 functions the device uses, and launches the render kernel.
+// No CPU rendering fallback exists here by design.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rt355.h"
+#include "rt_device.h"
+
+using namespace rt355;
+
+struct rt_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t upload_stream = nullptr;  // rt_set_random (other thread)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool timing_valid = false;
+
+  // skybox
+  float4 *d_hdri = nullptr;
+  uint32_t hdri_w = 0, hdri_h = 0;
+  // random texture: two device copies; `rnd_cur` is the one frames read
+  std::mutex rnd_mutex;
+  float *d_rnd[2] = {nullptr, nullptr};
+  size_t rnd_cap[2] = {0, 0};
+  uint32_t rnd_w[2] = {0, 0}, rnd_h[2] = {0, 0};
+  hipEvent_t rnd_last_use[2] = {nullptr, nullptr};
+  bool rnd_used[2] = {false, false};
+  int rnd_cur = -1;
+  // scene
+  float4 *d_scene = nullptr;
+  size_t scene_cap = 0;
+  DeviceScene scene{};
+  bool have_scene = false;
+  rt_wire_config config{};
+  // per-frame camera values (ray.hlsl:16-29)
+  f3 cam_pos{}, cam_right{}, cam_neg_up{}, top_left{};
+  float vp_width = 0, vp_height = 0;
+  // target
+  uint32_t width = 0, height = 0;
+  uint32_t rank = 0, world = 1, strip_rows = 8, local_rows = 0;
+  uint32_t out_flags = RT_OUT_RGBA8 | RT_OUT_RGBF32;
+  int accum_mode = RT_ACCUM_SRGB8;
+  uint32_t *d_rgba8 = nullptr;
+  float *d_rgbf32 = nullptr;
+  float *d_hist_f32 = nullptr;
+  uint32_t *d_segments = nullptr;
+  int32_t *d_hits = nullptr;
+  uint32_t hits_limit = 0;  // reflection_limit the hits buffer was sized for
+  unsigned long long *d_counters = nullptr;
+  float *d_lut = nullptr;
+  int variant = 0;
+  rt_stats stats{};
+  std::string error;
+};
+
+namespace {
+
+int fail(rt_context *ctx, int code, const char *fmt, ...) {
+  if (ctx) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    ctx->error = buf;
+  }
+  return code;
+}
+
+#define RT_HIP(ctx, call)                                                                         \
+  do {                                                                                            \
+    hipError_t e_ = (call);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE,          \
+                  "%s failed: %s", #call, hipGetErrorString(e_));                                 \
+  } while (0)
+
+uint32_t count_local_rows(uint32_t height, uint32_t rank, uint32_t world, uint32_t strip) {
+  uint32_t rows = 0;
+  for (uint32_t y0 = 0, s = 0; y0 < height; y0 += strip, ++s) {
+    if (s % world == rank) rows += (height - y0 < strip) ? height - y0 : strip;
+  }
+  return rows;
+}
+
+void free_target(rt_context *ctx) {
+  (void)hipFree(ctx->d_rgba8);
+  (void)hipFree(ctx->d_rgbf32);
+  (void)hipFree(ctx->d_hist_f32);
+  (void)hipFree(ctx->d_segments);
+  (void)hipFree(ctx->d_hits);
+  ctx->d_rgba8 = nullptr;
+  ctx->d_rgbf32 = nullptr;
+  ctx->d_hist_f32 = nullptr;
+  ctx->d_segments = nullptr;
+  ctx->d_hits = nullptr;
+  ctx->hits_limit = 0;
+}
+
+// (re)allocate per-pixel buffers for the current size / partition / outputs / accum mode
+int alloc_target(rt_context *ctx) {
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_target(ctx);
+  ctx->local_rows = count_local_rows(ctx->height, ctx->rank, ctx->world, ctx->strip_rows);
+  const size_t px = static_cast<size_t>(ctx->local_rows) * ctx->width;
+  if (px == 0) return RT_OK;
+  RT_HIP(ctx, hipMalloc(&ctx->d_rgba8, px * 4));
+  RT_HIP(ctx, hipMemsetAsync(ctx->d_rgba8, 0, px * 4, ctx->stream));
+  if (ctx->out_flags & RT_OUT_RGBF32) RT_HIP(ctx, hipMalloc(&ctx->d_rgbf32, px * 12));
+  if (ctx->accum_mode == RT_ACCUM_FLOAT32) {
+    RT_HIP(ctx, hipMalloc(&ctx->d_hist_f32, px * 12));
+    RT_HIP(ctx, hipMemsetAsync(ctx->d_hist_f32, 0, px * 12, ctx->stream));
+  }
+  if (ctx->out_flags & RT_OUT_SEGMENTS) RT_HIP(ctx, hipMalloc(&ctx->d_segments, px * 4));
+  return RT_OK;
+}
+
+int ensure_hits(rt_context *ctx, uint32_t limit) {
+  if (!(ctx->out_flags & RT_OUT_HITS)) return RT_OK;
+  if (ctx->d_hits && ctx->hits_limit >= limit) return RT_OK;
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(ctx->d_hits);
+  ctx->d_hits = nullptr;
+  const size_t n = static_cast<size_t>(ctx->local_rows) * ctx->width * (limit ? limit : 1);
+  if (n) RT_HIP(ctx, hipMalloc(&ctx->d_hits, n * 4));
+  ctx->hits_limit = limit;
+  return RT_OK;
+}
+
+// ray.hlsl:16-29 — the part of create_ray that does not depend on the pixel.
+void camera_setup(rt_context *ctx) {
+  const rt_wire_config &c = ctx->config;
+  const f3 position = mk3(c.position[0], c.position[1], c.position[2]);
+  const f3 forward = mk3(c.forward[0], c.forward[1], c.forward[2]);
+  const f3 right = mk3(c.right[0], c.right[1], c.right[2]);
+  const f3 up = mk3(c.up[0], c.up[1], c.up[2]);
+  const float fov_rad = (c.fov * kPi) * kInv180;
+  const float half_width = tan_spec(fov_rad * 0.5f);
+  const float half_height = (half_width * static_cast<float>(c.height)) / static_cast<float>(c.width);
+  const f3 center = position - forward;
+  const f3 left = fma3(right, -half_width, center);
+  const f3 top = fma3(up, half_height, center);
+  ctx->top_left = (left + top) - center;
+  ctx->vp_width = half_width * 2.0f;
+  ctx->vp_height = half_height * 2.0f;
+  ctx->cam_pos = position;
+  ctx->cam_right = right;
+  ctx->cam_neg_up = -up;
+}
+
+template <typename T>
+int read_back(rt_context *ctx, const T *src, void *dst, size_t bytes, size_t elem_bytes, const char *what) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!dst) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "%s: dst is NULL", what);
+  if (!src) return fail(ctx, RT_ERR_NOT_READY, "%s: output not enabled or no target allocated", what);
+  const size_t need = static_cast<size_t>(ctx->local_rows) * ctx->width * elem_bytes;
+  if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "%s: %zu bytes given, %zu expected", what, bytes, need);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rt_abi_version(void) { return RT355_ABI_VERSION; }
+
+int rt_create(int device_id, rt_context **out_ctx) {
+  if (!out_ctx) return RT_ERR_INVALID_ARGUMENT;
+  *out_ctx = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return RT_ERR_NO_DEVICE;
+  rt_context *ctx = new (std::nothrow) rt_context();
+  if (!ctx) return RT_ERR_OUT_OF_MEMORY;
+  ctx->device = device_id;
+  auto bail = [&](int code) {
+    rt_destroy(ctx);
+    return code;
+  };
+  if (hipSetDevice(device_id) != hipSuccess) return bail(RT_ERR_NO_DEVICE);
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(RT_ERR_DEVICE);
+  if (hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(RT_ERR_DEVICE);
+  if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess)
+    return bail(RT_ERR_DEVICE);
+  for (int i = 0; i < 2; ++i)
+    if (hipEventCreateWithFlags(&ctx->rnd_last_use[i], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
+  if (hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(RT_ERR_OUT_OF_MEMORY);
+  if (hipMalloc(&ctx->d_lut, 256 * sizeof(float)) != hipSuccess) return bail(RT_ERR_OUT_OF_MEMORY);
+  float lut[256];
+  for (uint32_t b = 0; b < 256; ++b) lut[b] = srgb8_decode_spec(b);
+  if (hipMemcpy(ctx->d_lut, lut, sizeof lut, hipMemcpyHostToDevice) != hipSuccess) return bail(RT_ERR_DEVICE);
+  *out_ctx = ctx;
+  return RT_OK;
+}
+
+int rt_destroy(rt_context *ctx) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
+  free_target(ctx);
+  (void)hipFree(ctx->d_hdri);
+  (void)hipFree(ctx->d_rnd[0]);
+  (void)hipFree(ctx->d_rnd[1]);
+  (void)hipFree(ctx->d_scene);
+  (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_lut);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->rnd_last_use[i]) (void)hipEventDestroy(ctx->rnd_last_use[i]);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
+  delete ctx;
+  return RT_OK;
+}
+
+int rt_set_skybox(rt_context *ctx, uint32_t width, uint32_t height, const float *rgba32f) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!rgba32f || !width || !height) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_skybox: empty image");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t bytes = static_cast<size_t>(width) * height * 16;
+  if (static_cast<size_t>(ctx->hdri_w) * ctx->hdri_h != static_cast<size_t>(width) * height) {
+    (void)hipFree(ctx->d_hdri);
+    ctx->d_hdri = nullptr;
+    ctx->hdri_w = ctx->hdri_h = 0;
+    RT_HIP(ctx, hipMalloc(&ctx->d_hdri, bytes));
+  }
+  RT_HIP(ctx, hipMemcpy(ctx->d_hdri, rgba32f, bytes, hipMemcpyHostToDevice));
+  ctx->hdri_w = width;
+  ctx->hdri_h = height;
+  return RT_OK;
+}
+
+int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float *r32f) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!r32f || !width || !height) return RT_ERR_INVALID_ARGUMENT;  // no ctx->error write: other thread
+  if (hipSetDevice(ctx->device) != hipSuccess) return RT_ERR_DEVICE;
+  // Fill the copy no frame is reading, then publish it.  A frame launched meanwhile keeps
+  // the old copy; one that used the target copy earlier is waited for on the upload stream.
+  int target;
+  bool wait_use;
+  {
+    std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
+    target = (ctx->rnd_cur == 0) ? 1 : 0;
+    wait_use = ctx->rnd_used[target];
+  }
+  const size_t bytes = static_cast<size_t>(width) * height * 4;
+  if (wait_use && hipStreamWaitEvent(ctx->upload_stream, ctx->rnd_last_use[target], 0) != hipSuccess)
+    return RT_ERR_DEVICE;
+  if (ctx->rnd_cap[target] < bytes) {
+    if (hipStreamSynchronize(ctx->upload_stream) != hipSuccess) return RT_ERR_DEVICE;
+    if (wait_use && hipEventSynchronize(ctx->rnd_last_use[target]) != hipSuccess) return RT_ERR_DEVICE;
+    (void)hipFree(ctx->d_rnd[target]);
+    ctx->d_rnd[target] = nullptr;
+    ctx->rnd_cap[target] = 0;
+    if (hipMalloc(&ctx->d_rnd[target], bytes) != hipSuccess) return RT_ERR_OUT_OF_MEMORY;
+    ctx->rnd_cap[target] = bytes;
+  }
+  if (hipMemcpyAsync(ctx->d_rnd[target], r32f, bytes, hipMemcpyHostToDevice, ctx->upload_stream) != hipSuccess)
+    return RT_ERR_DEVICE;
+  if (hipStreamSynchronize(ctx->upload_stream) != hipSuccess) return RT_ERR_DEVICE;
+  {
+    std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
+    ctx->rnd_w[target] = width;
+    ctx->rnd_h[target] = height;
+    ctx->rnd_cur = target;
+  }
+  return RT_OK;
+}
+
+int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, const void *lights,
+                 uint32_t light_count, const void *config112) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!config112 || (!objects && object_count)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_scene: NULL blob");
+  (void)lights;       // uploaded by the reference (connection.rs:379) but never read by the
+  (void)light_count;  // shader (inputs.hlsl:67 has no use) — accepted and ignored
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  std::memcpy(&ctx->config, config112, sizeof ctx->config);
+  if (!ctx->config.width || !ctx->config.height)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_scene: Config has a zero width or height");
+  camera_setup(ctx);
+
+  // Re-lay the AoS wire records out for the kernel (rt_device.h).
+  const auto *wire = static_cast<const uint8_t *>(objects);
+  std::vector<float4> sph, pl_a, pl_b, mat0(object_count), mat1(object_count);
+  std::vector<int> sph_obj;
+  for (uint32_t i = 0; i < object_count; ++i) {
+    rt_wire_object o;
+    std::memcpy(&o, wire + static_cast<size_t>(i) * RT355_OBJECT_STRIDE, sizeof o);
+    if (o.option == 0u) {  // ray.hlsl:53-68
+      sph.push_back(make_float4(o.center[0], o.center[1], o.center[2], o.f32_data * o.f32_data));
+      sph_obj.push_back(static_cast<int>(i));
+    } else if (o.option == 1u) {  // ray.hlsl:69-94
+      pl_a.push_back(make_float4(o.center[0], o.center[1], o.center[2], o.f32_data));
+      pl_b.push_back(make_float4(o.vec_data[0], o.vec_data[1], o.vec_data[2], u2f(i)));
+    }  // any other option never intersects (ray.hlsl:53,69)
+    float inv_exp = 0.0f;
+    if (o.roughness != 0.0f) {  // random.hlsl:30-33
+      const float smoothness = 1.0f - o.roughness;
+      const float phong_alpha = pow_spec(1000.0f, smoothness * smoothness);
+      inv_exp = 1.0f / (phong_alpha + 1.0f);
+    }
+    mat0[i] = make_float4(o.colour[0] * 2.0f, o.colour[1] * 2.0f, o.colour[2] * 2.0f, o.roughness);
+    mat1[i] = make_float4(o.emission[0] * o.emission_strength, o.emission[1] * o.emission_strength,
+                          o.emission[2] * o.emission_strength, inv_exp);
+  }
+  const size_t n_sph = sph.size(), n_pl = pl_a.size();
+  const size_t sph_obj_rec = (n_sph + 3) / 4;  // ints packed into float4 records
+  const size_t total = n_sph + sph_obj_rec + 2 * n_pl + 2 * static_cast<size_t>(object_count) + 1;
+  std::vector<float4> blob(total, make_float4(0, 0, 0, 0));
+  size_t off = 0;
+  const size_t off_sph = off;
+  if (n_sph) std::memcpy(&blob[off], sph.data(), n_sph * 16);
+  off += n_sph;
+  const size_t off_sobj = off;
+  if (n_sph) std::memcpy(&blob[off], sph_obj.data(), n_sph * 4);
+  off += sph_obj_rec;
+  const size_t off_pla = off;
+  if (n_pl) std::memcpy(&blob[off], pl_a.data(), n_pl * 16);
+  off += n_pl;
+  const size_t off_plb = off;
+  if (n_pl) std::memcpy(&blob[off], pl_b.data(), n_pl * 16);
+  off += n_pl;
+  const size_t off_m0 = off;
+  if (object_count) std::memcpy(&blob[off], mat0.data(), static_cast<size_t>(object_count) * 16);
+  off += object_count;
+  const size_t off_m1 = off;
+  if (object_count) std::memcpy(&blob[off], mat1.data(), static_cast<size_t>(object_count) * 16);
+
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old scene
+  if (ctx->scene_cap < total) {
+    (void)hipFree(ctx->d_scene);
+    ctx->d_scene = nullptr;
+    ctx->scene_cap = 0;
+    RT_HIP(ctx, hipMalloc(&ctx->d_scene, total * 16));
+    ctx->scene_cap = total;
+  }
+  RT_HIP(ctx, hipMemcpy(ctx->d_scene, blob.data(), total * 16, hipMemcpyHostToDevice));
+  ctx->scene.sph = ctx->d_scene + off_sph;
+  ctx->scene.sph_obj = reinterpret_cast<const int *>(ctx->d_scene + off_sobj);
+  ctx->scene.pl_a = ctx->d_scene + off_pla;
+  ctx->scene.pl_b = ctx->d_scene + off_plb;
+  ctx->scene.mat0 = ctx->d_scene + off_m0;
+  ctx->scene.mat1 = ctx->d_scene + off_m1;
+  ctx->scene.n_sph = static_cast<uint32_t>(n_sph);
+  ctx->scene.n_pl = static_cast<uint32_t>(n_pl);
+  ctx->scene.n_obj = object_count;
+  ctx->have_scene = true;
+  ctx->stats.object_count = object_count;
+  ctx->stats.sphere_count = ctx->scene.n_sph;
+  ctx->stats.plane_count = ctx->scene.n_pl;
+  return RT_OK;
+}
+
+int rt_resize(rt_context *ctx, uint32_t width, uint32_t height) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!width || !height) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_resize: zero size");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->width = width;
+  ctx->height = height;
+  return alloc_target(ctx);
+}
+
+int rt_set_partition(rt_context *ctx, uint32_t rank, uint32_t world, uint32_t strip_rows) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!world || rank >= world || !strip_rows)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_partition: rank %u / world %u / strip %u", rank, world, strip_rows);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->rank = rank;
+  ctx->world = world;
+  ctx->strip_rows = strip_rows;
+  return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
+}
+
+int rt_set_accum_mode(rt_context *ctx, int mode) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (mode != RT_ACCUM_SRGB8 && mode != RT_ACCUM_FLOAT32) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown accumulation mode %d", mode);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->accum_mode = mode;
+  return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
+}
+
+int rt_set_outputs(rt_context *ctx, uint32_t out_flags) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->out_flags = out_flags | RT_OUT_RGBA8;
+  return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
+}
+
+/* Undocumented in the reference: selects the kernel variant (0 LDS-staged geometry,
+ * 1 scalar-cache geometry).  Used by the benchmark to compare both. */
+int rt_set_variant(rt_context *ctx, int variant) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  ctx->variant = variant;
+  return RT_OK;
+}
+
+int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progressive_count) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!ctx->d_hdri) return fail(ctx, RT_ERR_NOT_READY, "rt_render: no skybox (rt_set_skybox)");
+  if (!ctx->have_scene) return fail(ctx, RT_ERR_NOT_READY, "rt_render: no scene (rt_set_scene)");
+  if (!ctx->width) return fail(ctx, RT_ERR_NOT_READY, "rt_render: no target (rt_resize)");
+  if (ctx->config.width != ctx->width || ctx->config.height != ctx->height)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render: Config is %ux%u but the target is %ux%u",
+                ctx->config.width, ctx->config.height, ctx->width, ctx->height);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = ensure_hits(ctx, ctx->config.reflection_limit);
+  if (rc != RT_OK) return rc;
+
+  FrameParams fp{};
+  int rnd;
+  {
+    std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
+    rnd = ctx->rnd_cur;
+    if (rnd >= 0) {
+      fp.rnd = ctx->d_rnd[rnd];
+      fp.rnd_w = ctx->rnd_w[rnd];
+      fp.rnd_h = ctx->rnd_h[rnd];
+      ctx->rnd_used[rnd] = true;
+    }
+  }
+  if (rnd < 0) return fail(ctx, RT_ERR_NOT_READY, "rt_render: no random texture (rt_set_random)");
+  fp.width = ctx->width;
+  fp.height = ctx->height;
+  fp.reflection_limit = ctx->config.reflection_limit;
+  fp.progressive_count = progressive_count;
+  fp.jitter_x = jitter_x;
+  fp.jitter_y = jitter_y;
+  fp.opacity = 1.0f / static_cast<float>(progressive_count + 1u);  // frag.hlsl:61
+  fp.keep = 1.0f - fp.opacity;
+  fp.cam_pos = ctx->cam_pos;
+  fp.cam_right = ctx->cam_right;
+  fp.cam_neg_up = ctx->cam_neg_up;
+  fp.top_left = ctx->top_left;
+  fp.vp_width = ctx->vp_width;
+  fp.vp_height = ctx->vp_height;
+  fp.hdri = ctx->d_hdri;
+  fp.hdri_w = ctx->hdri_w;
+  fp.hdri_h = ctx->hdri_h;
+  fp.rank = ctx->rank;
+  fp.world = ctx->world;
+  fp.strip_rows = ctx->strip_rows;
+  fp.local_rows = ctx->local_rows;
+  fp.rgba8 = ctx->d_rgba8;
+  fp.rgbf32 = ctx->d_rgbf32;
+  fp.hist_f32 = ctx->d_hist_f32;
+  fp.segments = ctx->d_segments;
+  fp.hits = ctx->d_hits;
+  fp.counters = ctx->d_counters;
+  fp.srgb_lut = ctx->d_lut;
+  fp.accum_mode = ctx->accum_mode;
+
+  RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  RT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  LaunchConfig lc{ctx->variant};
+  const int lrc = launch_render(ctx->scene, fp, lc, ctx->stream);
+  if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
+  RT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  RT_HIP(ctx, hipEventRecord(ctx->rnd_last_use[rnd], ctx->stream));
+  ctx->timing_valid = true;
+  ctx->stats.frames += 1;
+  return RT_OK;
+}
+
+int rt_render_frame(rt_context *ctx, const void *framedata16) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!framedata16) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_frame: NULL FrameData");
+  rt_wire_frame f;
+  std::memcpy(&f, framedata16, sizeof f);
+  return rt_render(ctx, f.jitter[0], f.jitter[1], f.progressive_count);
+}
+
+int rt_sync(rt_context *ctx) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_read_rgba8(rt_context *ctx, void *dst, size_t bytes) {
+  return read_back(ctx, ctx ? ctx->d_rgba8 : nullptr, dst, bytes, 4, "rt_read_rgba8");
+}
+int rt_read_rgbf32(rt_context *ctx, float *dst, size_t bytes) {
+  return read_back(ctx, ctx ? ctx->d_rgbf32 : nullptr, dst, bytes, 12, "rt_read_rgbf32");
+}
+int rt_read_segments(rt_context *ctx, uint32_t *dst, size_t bytes) {
+  return read_back(ctx, ctx ? ctx->d_segments : nullptr, dst, bytes, 4, "rt_read_segments");
+}
+int rt_read_hits(rt_context *ctx, int32_t *dst, size_t bytes) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  return read_back(ctx, ctx->d_hits, dst, bytes, 4 * static_cast<size_t>(ctx->config.reflection_limit), "rt_read_hits");
+}
+
+int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!src) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_write_history_rgba8: NULL");
+  if (!ctx->d_rgba8) return fail(ctx, RT_ERR_NOT_READY, "rt_write_history_rgba8: no target");
+  const size_t need = static_cast<size_t>(ctx->local_rows) * ctx->width * 4;
+  if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_write_history_rgba8: %zu bytes given, %zu expected", bytes, need);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipMemcpyAsync(ctx->d_rgba8, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+int rt_get_device_buffers(rt_context *ctx, rt_device_buffers *out) {
+  if (!ctx || !out) return RT_ERR_INVALID_ARGUMENT;
+  out->rgba8 = ctx->d_rgba8;
+  out->rgbf32 = ctx->d_rgbf32;
+  out->segments = ctx->d_segments;
+  out->hits = ctx->d_hits;
+  out->stream = ctx->stream;
+  out->width = ctx->width;
+  out->local_rows = ctx->local_rows;
+  return RT_OK;
+}
+
+int rt_get_stats(rt_context *ctx, rt_stats *out) {
+  if (!ctx || !out) return RT_ERR_INVALID_ARGUMENT;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->timing_valid) {
+    unsigned long long c[2] = {0, 0};
+    RT_HIP(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    ctx->stats.last_segments = c[0];
+    ctx->stats.last_rough_hits = c[1];
+    float ms = 0.0f;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    ctx->stats.last_kernel_ms = ms;
+  }
+  ctx->stats.last_pixels = static_cast<uint64_t>(ctx->local_rows) * ctx->width;
+  ctx->stats.width = ctx->width;
+  ctx->stats.height = ctx->height;
+  ctx->stats.local_rows = ctx->local_rows;
+  *out = ctx->stats;
+  return RT_OK;
+}
+
+const char *rt_last_error(rt_context *ctx) { return ctx ? ctx->error.c_str() : "rt_context is NULL"; }
+
+int rt_selftest_math_unary(rt_context *ctx, int op, const float *x, float *y, size_t n) {
+  if (!ctx || !x || !y) return RT_ERR_INVALID_ARGUMENT;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  float *dx = nullptr, *dy = nullptr;
+  RT_HIP(ctx, hipMalloc(&dx, n * 4 + 4));
+  RT_HIP(ctx, hipMalloc(&dy, n * 4 + 4));
+  RT_HIP(ctx, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
+  const int rc = launch_math_unary(op, dx, dy, n, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (rc == 0 && e == hipSuccess) e = hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(dx);
+  (void)hipFree(dy);
+  if (rc != 0 || e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "math self-test failed");
+  return RT_OK;
+}
+
+int rt_selftest_math_binary(rt_context *ctx, int op, const float *a, const float *b, float *y, size_t n) {
+  if (!ctx || !a || !b || !y) return RT_ERR_INVALID_ARGUMENT;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  float *da = nullptr, *db = nullptr, *dy = nullptr;
+  RT_HIP(ctx, hipMalloc(&da, n * 4 + 4));
+  RT_HIP(ctx, hipMalloc(&db, n * 4 + 4));
+  RT_HIP(ctx, hipMalloc(&dy, n * 4 + 4));
+  RT_HIP(ctx, hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+  RT_HIP(ctx, hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
+  const int rc = launch_math_binary(op, da, db, dy, n, ctx->stream);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (rc == 0 && e == hipSuccess) e = hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dy);
+  if (rc != 0 || e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "math self-test failed");
+  return RT_OK;
+}
+
+}  // extern "C"
