@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""rt355 benchmark — BASELINE.json metric: Mrays/s at 1920x1080, 64 spheres, 8 bounces.
+
+A step is one frame (1 spp, progressive_count 0) of BASELINE config 2 through the C-ABI:
+64 spheres + the ground plane (65 live objects), 2048x1024 RGBA32F skybox, 600x600 random
+texture, all resident in HBM before the timed region.  A ray = one executed iteration of
+the bounce loop (frag.hlsl:36-43).  N GPUs split the same frame into row strips
+(strong scaling) and gather the sRGB8 texels on rank 0 over RCCL.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the render kernel's ALGORITHMIC bytes
+(8 B/pixel + 16 B/segment + 8 B/rough hit) against the 8 TB/s HBM peak, from
+per-launch HIP-event durations taken inside the timed region; `valu` prices the algorithmic
+flops against the 157.3 TFLOP/s FP32 vector peak (the bound that actually binds — DESIGN.md).
+`cpu_baseline` is the CPU oracle (OpenMP) on the same frame, reported, not targeted.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
+VALU_PEAK_TFLOPS = 157.3    # FP32 vector peak
+
+
+def algorithmic_bytes(pixels, segments, rough):
+    return 8.0 * pixels + 16.0 * segments + 8.0 * rough
+
+
+def algorithmic_flops(pixels, segments, n_objects):
+    return segments * (25.0 * n_objects + 200.0) + 60.0 * pixels
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spheres", type=int, default=64)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--slots", type=int, default=0, help="object slots passed (0 = live count; 80 = reference padding)")
+    ap.add_argument("--sky", type=int, default=2048, help="skybox width (height = width/2)")
+    ap.add_argument("--variant", type=int, default=2)
+    ap.add_argument("--refill-min", type=int, default=16)
+    ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--strip-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import cases
+    from rsraytracingv3_amd import Connection, Device, RandomTexture, RenderTarget, synth
+    from rsraytracingv3_amd import _native as N
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if args.steps > 512:
+        raise SystemExit("bench.py: --steps must be <= 512 (per-frame event ring)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    scene = cases.spheres_scene(args.spheres, args.bounces, seed=42, request=max(100, int(args.spheres * 1.6))) \
+        if args.spheres <= 64 else cases.stress_scene(args.spheres, args.bounces)
+    n_objects = len(scene.objects) if args.slots == 0 else args.slots
+    sky = synth.procedural_skybox(args.sky, args.sky // 2)
+    rnd = synth.random_texture(1)
+    jit = synth.jitter_sequence(42, args.steps + args.warmup)
+
+    dev = Device(local_rank)
+    dev.set_outputs(N.RT_OUT_RGBA8)
+    dev.set_variant(args.variant)
+    dev.set_option(N.RT_OPT_REFILL_MIN, args.refill_min)
+    dev.set_option(N.RT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
+    target = RenderTarget.new(dev, (W, H))
+    rt = RandomTexture(dev)
+    rt.write(rnd)
+    conn = Connection(scene, dev, sky, rt, max_objects=("live" if args.slots == 0 else args.slots))
+    conn.update_buffers((W, H), scene, (0.0, 0.0))
+
+    tiles = None
+    if world > 1:
+        from rsraytracingv3_amd.distributed import TileParallelRenderer
+        tiles = TileParallelRenderer(dev, W, H, args.strip_rows)
+
+    def step(k):
+        if tiles is None:
+            conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
+            conn.frame_data.progressive_count = 0
+            conn.draw()
+        else:
+            stacked = tiles.render(conn, jit[k], 0)
+            if rank == 0:
+                tiles.gatherer.assemble(stacked)  # the assembled frame of the previous gather
+
+    def fence():
+        if tiles is not None:
+            tiles.finish()
+        dev.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    # per-launch totals and HIP-event kernel durations of the timed region
+    seg = np.zeros(args.steps, np.uint64)
+    rough = np.zeros(args.steps, np.uint64)
+    kms = np.zeros(args.steps, np.float32)
+    dev.call("rt_get_frame_history", args.steps, seg.ctypes.data_as(C.c_void_p), rough.ctypes.data_as(C.c_void_p),
+             kms.ctypes.data_as(C.c_void_p))
+    st = dev.stats()
+    local = torch.tensor([elapsed, float(seg.sum()), float(rough.sum()), float(kms.sum()), float(st.last_pixels)],
+                         dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = local.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = local.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+        total_seg, total_rough, total_px = float(sm[1]), float(sm[2]), float(sm[4])
+    else:
+        total_seg, total_rough, total_px = float(local[1]), float(local[2]), float(local[4])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    steps = args.steps
+    value = total_seg / elapsed / 1e6
+    # roofline of the dominant (only) kernel, rank 0's launches
+    k_sec = float(kms.sum()) * 1e-3
+    px_launch = float(st.last_pixels)
+    b_alg = algorithmic_bytes(px_launch * steps, float(seg.sum()), float(rough.sum()))
+    f_alg = algorithmic_flops(px_launch * steps, float(seg.sum()), n_objects)
+    achieved = b_alg / k_sec / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+    if os.path.exists(tpath) and world == 1:
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "Mrays/s at 1920x1080, 64 spheres, 8 bounces",
+        "value": round(value, 2),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%dx%d, %d spheres + ground plane (%d object slots), %d bounces, 1 spp, %dx%d RGBA32F skybox"
+                        % (W, H, args.spheres, n_objects, args.bounces, args.sky, args.sky // 2),
+            "partition": "row strips of %d, round-robin over %d GPU(s)%s" % (args.strip_rows, world,
+                                                                          ", RCCL gather to rank 0" if world > 1 else ""),
+            "kernel_variant": args.variant,
+            "segments_per_pixel": round(total_seg / (float(W) * H * steps), 4),
+            "mpixels_per_s": round(W * H * steps / elapsed / 1e6, 2),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 2),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "traffic": traffic,
+            "kernel": "render_persistent" if args.variant == 2 else "render_tiles",
+            "avg_launch_ms": round(float(kms.mean()), 5),
+            "alg_bytes_per_launch": round(b_alg / steps, 1),
+            "note": "VALU-bound path (SURVEY §8d): see 'valu' for the binding roofline",
+        },
+        "valu": {
+            "achieved": round(f_alg / k_sec / 1e12, 3),
+            "peak": VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": round(f_alg / k_sec / 1e12 / VALU_PEAK_TFLOPS, 5),
+            "alg_flops_per_launch": round(f_alg / steps, 1),
+            "kernel_mrays_per_s": round(float(seg.sum()) / k_sec / 1e6, 2),
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle
+        rows = (0, H) if args.cpu_rows <= 0 else ((H - args.cpu_rows) // 2, (H - args.cpu_rows) // 2 + args.cpu_rows)
+        if args.slots == 0:
+            objects, count = scene.live_object_bytes(), len(scene.objects)
+        else:
+            objects, count = scene.as_bytes(W, H, args.slots)[0], args.slots
+        # the GPU box gives one GPU a share of 16 host cores; never use more than that
+        threads = max(1, min(oracle.max_threads(), os.cpu_count() or 1, 16))
+        cfg = scene.config_bytes(W, H)
+        oracle.render(objects, count, cfg, jit[args.warmup], 0, sky, rnd, rows=(rows[0], rows[0] + 8),
+                      threads=threads, want_hits=False)  # warm the thread pool
+        cseg, cdt, frames, first_seg = 0, 0.0, 0, None
+        while cdt < 12.0 and frames < args.steps:  # a bounded sample: whole frames until ~12 s of wall time
+            k = args.warmup + frames
+            c0 = time.perf_counter()
+            fr = oracle.render(objects, count, cfg, jit[k], 0, sky, rnd, rows=rows, threads=threads, want_hits=False)
+            cdt += time.perf_counter() - c0
+            fs = int(fr.segments[rows[0]:rows[1]].sum())
+            first_seg = fs if first_seg is None else first_seg
+            cseg += fs
+            frames += 1
+        out["cpu_baseline"] = {
+            "value": round(cseg / cdt / 1e6, 3),
+            "unit": "Mrays/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": "%d frame(s), rows %d..%d of the same %dx%d workload (%d segments, %.1f s wall, %d OpenMP "
+                      "threads), CPU oracle oracle/rt_oracle.c; the reference itself cannot run here (no "
+                      "Rust/wgpu/Vulkan)" % (frames, rows[0], rows[1], W, H, cseg, cdt, threads),
+        }
+        # cross-check: the GPU counted the same number of segments for that frame
+        out["cpu_baseline"]["segments_match_gpu"] = bool(args.cpu_rows <= 0 and first_seg == int(seg[0]))
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

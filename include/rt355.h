@@ -135,16 +135,35 @@ RT355_API int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t by
 
 RT355_API int rt_get_device_buffers(rt_context *ctx, rt_device_buffers *out);
 RT355_API int rt_get_stats(rt_context *ctx, rt_stats *out);
+/* Per-frame totals and HIP-event kernel times of the most recent n frames (oldest first;
+ * n <= 512).  Any output pointer may be NULL.  Waits for the stream. */
+RT355_API int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segments, uint64_t *rough_hits,
+                                   float *kernel_ms);
+/* Order all of the context's work on a caller-owned hipStream_t (e.g. the stream an RCCL
+ * gather is issued on).  The default is a private non-blocking stream. */
+RT355_API int rt_set_stream(rt_context *ctx, void *hip_stream);
+/* Render into caller-owned device buffers of local_rows x width texels (rgba8: 4 B each,
+ * rgbf32: 12 B each or NULL).  d_history_rgba8 is the previous frame's texels (NULL = the
+ * same buffer, in place).  Pass d_rgba8 = NULL to return to the context's own buffers.
+ * Takes effect at the next rt_render; does not synchronise. */
+RT355_API int rt_bind_outputs(rt_context *ctx, void *d_rgba8, void *d_history_rgba8, void *d_rgbf32);
 /* Text of the most recent error on this context (valid until the next call on it). */
 RT355_API const char *rt_last_error(rt_context *ctx);
 
-/* Kernel variant: 0 = sphere records staged in LDS (default), 1 = sphere records through the
- * scalar cache.  Results are identical; the benchmark compares their speed. */
-RT355_API int rt_set_variant(rt_context *ctx, int variant);
+/* Tuning knobs; results are bit-identical for every setting, only speed changes. */
+enum {
+  RT_OPT_VARIANT = 0,      /* 0 one 8x8 tile per wave, sphere records in LDS; 1 same, records through
+                              the scalar cache; 2 (default) resident waves that refill finished lanes */
+  RT_OPT_REFILL_MIN = 1,   /* variant 2: idle lanes a wave tolerates before pulling pixels (1..64) */
+  RT_OPT_BLOCKS_PER_CU = 2 /* variant 2: resident workgroups per CU (0 = occupancy query)       */
+};
+RT355_API int rt_set_option(rt_context *ctx, int option, int value);
+RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */
 
 /* Device self-test hooks used by the parity tests: evaluate the device build of the
  * specified math function over n host values (op: 0 sin 1 cos 2 tan 3 asin 4 log2
- * 5 exp2 6 sqrt; binary op: 0 atan2(a,b) 1 pow(a,b) 2 a/b). */
+ * 5 exp2 6 sqrt 7 the kernel's own sqrt; binary op: 0 atan2(a,b) 1 pow(a,b) 2 a/b). */
+RT355_API int rt_selftest_sqrt(rt_context *ctx, uint64_t *mismatches); /* kernel sqrt vs IEEE, every float */
 RT355_API int rt_selftest_math_unary(rt_context *ctx, int op, const float *x, float *y, size_t n);
 RT355_API int rt_selftest_math_binary(rt_context *ctx, int op, const float *a, const float *b, float *y, size_t n);
 

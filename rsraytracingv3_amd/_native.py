@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "librt355.so")
 RT_OK = 0
 RT_ACCUM_SRGB8, RT_ACCUM_FLOAT32 = 0, 1
 RT_OUT_RGBA8, RT_OUT_RGBF32, RT_OUT_SEGMENTS, RT_OUT_HITS = 1, 2, 4, 8
+RT_OPT_VARIANT, RT_OPT_REFILL_MIN, RT_OPT_BLOCKS_PER_CU = 0, 1, 2
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_NOT_READY",
                 -4: "RT_ERR_DEVICE", -5: "RT_ERR_OUT_OF_MEMORY"}
@@ -52,6 +53,8 @@ SIGNATURES = {
     "rt_set_accum_mode": (_i, [_vp, _i]),
     "rt_set_outputs": (_i, [_vp, _u32]),
     "rt_set_variant": (_i, [_vp, _i]),
+    "rt_set_option": (_i, [_vp, _i, _i]),
+    "rt_selftest_sqrt": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "rt_render": (_i, [_vp, _f, _f, _u32]),
     "rt_render_frame": (_i, [_vp, _vp]),
     "rt_sync": (_i, [_vp]),
@@ -62,6 +65,9 @@ SIGNATURES = {
     "rt_write_history_rgba8": (_i, [_vp, _vp, _sz]),
     "rt_get_device_buffers": (_i, [_vp, C.POINTER(RtDeviceBuffers)]),
     "rt_get_stats": (_i, [_vp, C.POINTER(RtStats)]),
+    "rt_get_frame_history": (_i, [_vp, _u32, _vp, _vp, _vp]),
+    "rt_set_stream": (_i, [_vp, _vp]),
+    "rt_bind_outputs": (_i, [_vp, _vp, _vp, _vp]),
     "rt_last_error": (C.c_char_p, [_vp]),
     "rt_selftest_math_unary": (_i, [_vp, _i, _vp, _vp, _sz]),
     "rt_selftest_math_binary": (_i, [_vp, _i, _vp, _vp, _vp, _sz]),

@@ -79,6 +79,9 @@ class Device:
     def set_variant(self, variant: int):
         self.call("rt_set_variant", variant)
 
+    def set_option(self, option: int, value: int):
+        self.call("rt_set_option", option, value)
+
     def sync(self):
         self.call("rt_sync")
 

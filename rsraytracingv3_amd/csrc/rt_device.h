@@ -48,20 +48,26 @@ struct FrameParams {
   // row-strip partition (rt_set_partition)
   uint32_t rank, world, strip_rows, local_rows;
   // outputs
-  uint32_t *rgba8;
+  uint32_t *rgba8;             // stored texels (written)
+  const uint32_t *hist_rgba8;  // previous frame's texels (read when progressive_count > 0); may alias rgba8
   float *rgbf32;    // may be null
   float *hist_f32;  // RT_ACCUM_FLOAT32 history, else null
   uint32_t *segments;  // may be null
   int32_t *hits;       // may be null
-  unsigned long long *counters;  // [0] segments, [1] rough hits
+  unsigned long long *counters;  // [0] segments, [1] rough hits, [2] tile counter (variant 2)
   const float *srgb_lut;         // 256 decoded values
   int accum_mode;
 };
 
 // kernels (rt_kernels.hip)
 struct LaunchConfig {
-  int variant;  // 0 = tile kernel, LDS-staged geometry; 1 = tile kernel, scalar-cache geometry
+  int variant;            // 0 tile kernel, LDS geometry; 1 tile kernel, scalar-cache geometry;
+                          // 2 persistent waves with lane refill, LDS geometry (default)
+  int refill_min;         // variant 2: idle lanes tolerated before a wave pulls new pixels
+  int persistent_blocks;  // variant 2: grid size (resident workgroups)
 };
+int persistent_blocks_per_cu(size_t lds_bytes);
+int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);
 int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream);

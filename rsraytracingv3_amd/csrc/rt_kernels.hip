@@ -1,14 +1,22 @@
 // rt_kernels.hip — gfx950 kernels of the rt355 render path.
 //
-// One lane = one pixel of frag.hlsl:48-66 (fs_main).  A wave owns an 8x8 pixel tile so the
-// 64 primary rays are coherent; a 256-thread workgroup stages the sphere records into LDS
-// once and every ray segment scans them from there (wave-uniform address -> LDS broadcast,
-// no bank conflicts).  Closest-hit selection follows ray.hlsl:97-107 exactly (App. B D10:
-// strict '<' in ascending object order == lexicographic min of (distance, index)).
+// One lane carries one pixel's path through frag.hlsl:48-66 (fs_main).  The sphere records of
+// the compiled scene are staged into LDS once per workgroup and every ray segment scans them
+// from there (wave-uniform address -> LDS broadcast, conflict free).  Closest-hit selection
+// follows ray.hlsl:97-107 exactly (App. B D10: strict '<' in ascending object order ==
+// lexicographic min of (distance, index)).
+//
+// Two launch shapes share the per-segment code:
+//   render_tiles       one 8x8 pixel tile per wave, lanes idle once their path has ended
+//                      (variants 0 / 1: sphere records from LDS / through the scalar cache)
+//   render_persistent  resident waves pull 8x8 tiles from a device counter and REFILL lanes
+//                      whose path ended with the next pixels (ballot + mbcnt rank), so the
+//                      object scan keeps all 64 lanes busy although path lengths vary 1..R
+//                      (variant 2, the default)
 //
 // The square root of the sphere test is only evaluated when some lane of the wave can still
-// accept the sphere (ballot over "discriminant >= 0 and the sphere is in front"): rejected
-// lanes of the reference never use the root, so skipping it is exact.
+// accept the sphere (ballot over "discriminant >= 0 and the sphere is in front"): lanes the
+// reference rejects never use the root, so skipping it is exact.
 #include <hip/hip_runtime.h>
 
 #include "rt_device.h"
@@ -18,7 +26,26 @@ namespace rt355 {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kTile = 8;  // 8x8 pixels per wave
+constexpr int kTile = 8;  // 8x8 pixels per tile / wave
+
+// Correctly rounded sqrt for x >= 2^-96 (also +0, +inf, NaN): v_sqrt_f32 is within 1 ulp, so
+// the IEEE result is one of {s-1ulp, s, s+1ulp}; the signs of the two fused residuals pick it
+// (the same selection hipcc's own expansion makes, without its pre-scaling of small inputs).
+// Below 2^-96 the residuals can underflow, so those inputs take hipcc's scaled expansion behind
+// a wave-uniform branch that is essentially never taken (0 < bits(x) < bits(2^-96) as one
+// unsigned compare).  Checked against the IEEE result for EVERY float by rt_selftest_sqrt.
+__device__ __forceinline__ float sqrt_rn(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __uint_as_float(__float_as_uint(s) - 1u);
+  const float su = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rd = fmaf(-sd, s, x);
+  const float ru = fmaf(-su, s, x);
+  float r = (rd <= 0.0f) ? sd : s;
+  r = (ru > 0.0f) ? su : r;
+  const bool tiny = (__float_as_uint(x) - 1u) < (0x0f800000u - 1u);
+  if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) r = tiny ? sqrtf(x) : r;
+  return r;
+}
 
 struct Rng {
   float seed, px, py;  // random.hlsl:1-2
@@ -71,27 +98,25 @@ struct Hit {
   bool plane;
 };
 
-// ray.hlsl:97-107 over the compiled scene.  GEOM_LDS: sphere records come from LDS.
-template <bool GEOM_LDS>
-__device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *lds_sph, f3 o, f3 d) {
+// ray.hlsl:97-107 over the compiled scene.
+__device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d) {
   float best = 1000000.0f;
   int slot = -1;
   const uint32_t n = sc.n_sph;
-  const float4 *sph = GEOM_LDS ? lds_sph : sc.sph;
   // One sphere of ray.hlsl:53-68.  q = discriminant/4 and dn = b/2 (exact power-of-two
   // scalings of the reference's b, c, discriminant), so t = -dn - sqrt(q) has the bits of
   // (-b - sqrt(disc)) / (2a).  A sphere can only be accepted when q >= 0 and dn < 0 (t > 0).
-#define RT_SPHERE_PRE(g, dn, q, cand)                                  \
-  const float nx##dn = o.x - g.x, ny##dn = o.y - g.y, nz##dn = o.z - g.z; \
-  const float dn = fmaf(d.z, nz##dn, fmaf(d.y, ny##dn, d.x * nx##dn));    \
+#define RT_SPHERE_PRE(g, dn, q, cand)                                                                  \
+  const float nx##dn = o.x - g.x, ny##dn = o.y - g.y, nz##dn = o.z - g.z;                              \
+  const float dn = fmaf(d.z, nz##dn, fmaf(d.y, ny##dn, d.x * nx##dn));                                 \
   const float q = fmaf(dn, dn, -(fmaf(nz##dn, nz##dn, fmaf(ny##dn, ny##dn, nx##dn * nx##dn)) - g.w)); \
   const bool cand = (q >= 0.0f) & (dn < 0.0f);
-#define RT_SPHERE_POST(idx, dn, q, cand)                               \
-  if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {                     \
-    const float t = -dn - sqrtf(q);                                    \
-    const bool acc = cand & (t >= kEpsilon) & (t < best);              \
-    best = acc ? t : best;                                             \
-    slot = acc ? static_cast<int>(idx) : slot;                         \
+#define RT_SPHERE_POST(idx, dn, q, cand)                  \
+  if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {        \
+    const float t = -dn - sqrt_rn(q);                     \
+    const bool acc = cand & (t >= kEpsilon) & (t < best); \
+    best = acc ? t : best;                                \
+    slot = acc ? static_cast<int>(idx) : slot;            \
   }
   uint32_t i = 0;
   for (; i + 4 <= n; i += 4) {
@@ -119,7 +144,7 @@ __device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *ld
   h.slot = slot;
   h.plane = false;
   h.obj = (slot >= 0) ? sc.sph_obj[slot] : -1;
-  for (uint32_t j = 0; j < sc.n_pl; ++j) {
+  for (uint32_t j = 0; j < sc.n_pl; ++j) {  // ray.hlsl:69-94
     const float4 a = sc.pl_a[j], b = sc.pl_b[j];
     const f3 c = mk3(a.x, a.y, a.z), nrm = mk3(b.x, b.y, b.z);
     const int idx = static_cast<int>(f2u(b.w));
@@ -141,6 +166,114 @@ __device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *ld
   return h;
 }
 
+// State of one pixel's path between two iterations of frag.hlsl:36-43.
+struct Path {
+  f3 o, d, energy, result;
+  Rng rng;
+  uint32_t p;      // local pixel index (local_row * width + x)
+  uint32_t seg;    // iterations executed so far
+  uint32_t rough;  // of which drew random() (rough hit)
+};
+
+// fs_main up to the call of trace_ray_with_reflections (frag.hlsl:49-57, ray.hlsl:31-37).
+__device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, uint32_t lrow, Path &s) {
+  // local row -> global row of the round-robin strip partition
+  const uint32_t y = ((lrow / fp.strip_rows) * fp.world + fp.rank) * fp.strip_rows + lrow % fp.strip_rows;
+  s.p = lrow * fp.width + x;
+  // D14: SV_POSITION.xy = pixel centre
+  const float pjx = (static_cast<float>(x) + 0.5f) + fp.jitter_x;
+  const float pjy = (static_cast<float>(y) + 0.5f) + fp.jitter_y;
+  const float cjx = pjx / static_cast<float>(fp.width), cjy = pjy / static_cast<float>(fp.height);
+  s.rng = Rng{42.0f, cjx, cjy};
+  f3 pw = fma3(fp.cam_right, cjx * fp.vp_width, fp.top_left);
+  pw = fma3(fp.cam_neg_up, cjy * fp.vp_height, pw);
+  s.o = fp.cam_pos;
+  s.d = normalize3(pw - fp.cam_pos);
+  s.energy = mk3(1.0f, 1.0f, 1.0f);
+  s.result = mk3(0.0f, 0.0f, 0.0f);
+  s.seg = 0;
+  s.rough = 0;
+}
+
+// One iteration of frag.hlsl:36-43 (ray_intersect + shade).  Returns whether the loop goes on.
+__device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *__restrict__ sph,
+                                          const FrameParams &fp, Path &s) {
+  const Hit h = intersect(sc, sph, s.o, s.d);
+  if (fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
+  s.seg += 1;
+  if (h.obj < 0) {  // frag.hlsl:14-17: miss -> skybox, energy 0, loop ends (|0| < EPSILON)
+    s.result = fma3(s.energy, sample_hdri(fp, s.d), s.result);
+    return false;
+  }
+  const f3 pos = fma3(s.d, h.t, s.o);
+  f3 nrm;
+  if (h.plane) {
+    const float4 b = sc.pl_b[h.slot];
+    nrm = mk3(b.x, b.y, b.z);  // ray.hlsl:43-45: stored normal, not renormalised
+  } else {
+    const float4 g = sph[h.slot];
+    nrm = normalize3(pos - mk3(g.x, g.y, g.z));
+  }
+  const float4 m0 = sc.mat0[h.obj], m1 = sc.mat1[h.obj];
+  s.o = fma3(nrm, 0.001f, pos);                   // frag.hlsl:21
+  const float k = 2.0f * dot3(nrm, s.d);          // reflect(), frag.hlsl:23
+  f3 nd = fma3(nrm, -k, s.d);
+  if (m0.w != 0.0f) {                             // random.hlsl:26-28
+    nd = hemisphere(fp, s.rng, nd, m1.w);
+    s.rough += 1;
+  }
+  s.d = nd;
+  const float cosine = saturate(dot3(nrm, s.d));
+  s.result = fma3(s.energy, mk3(m1.x, m1.y, m1.z), s.result);  // D1: energy before the update
+  s.energy = s.energy * (mk3(m0.x, m0.y, m0.z) * cosine);      // frag.hlsl:27
+  if (length3(s.energy) < kEpsilon) return false;              // frag.hlsl:40-42
+  return s.seg < fp.reflection_limit;
+}
+
+// frag.hlsl:60-65 + the Rgba8UnormSrgb store (D13).  At progressive_count 0 the history weight
+// is exactly 0, so the history is not read.
+__device__ __forceinline__ void path_end(const FrameParams &fp, const Path &s) {
+  const size_t p = s.p;
+  f3 prev = mk3(0.0f, 0.0f, 0.0f);
+  if (fp.progressive_count != 0u) {
+    if (fp.accum_mode == 1) {
+      prev = mk3(fp.hist_f32[3 * p], fp.hist_f32[3 * p + 1], fp.hist_f32[3 * p + 2]);
+    } else {
+      const uint32_t w = fp.hist_rgba8[p];
+      prev = mk3(fp.srgb_lut[w & 255u], fp.srgb_lut[(w >> 8) & 255u], fp.srgb_lut[(w >> 16) & 255u]);
+    }
+  }
+  const f3 mixed = fma3(s.result, fp.opacity, prev * fp.keep);
+  fp.rgba8[p] = srgb8_encode_spec(mixed.x) | (srgb8_encode_spec(mixed.y) << 8) |
+                (srgb8_encode_spec(mixed.z) << 16) | 0xff000000u;
+  if (fp.rgbf32) {
+    fp.rgbf32[3 * p] = mixed.x;
+    fp.rgbf32[3 * p + 1] = mixed.y;
+    fp.rgbf32[3 * p + 2] = mixed.z;
+  }
+  if (fp.hist_f32 && fp.accum_mode == 1) {
+    fp.hist_f32[3 * p] = mixed.x;
+    fp.hist_f32[3 * p + 1] = mixed.y;
+    fp.hist_f32[3 * p + 2] = mixed.z;
+  }
+  if (fp.segments) fp.segments[p] = s.seg;
+  if (fp.hits)  // iterations that never ran are marked -2
+    for (uint32_t i = s.seg; i < fp.reflection_limit; ++i) fp.hits[p * fp.reflection_limit + i] = -2;
+}
+
+// one atomic per wave for the frame totals
+__device__ __forceinline__ void add_totals(const FrameParams &fp, uint32_t lane, uint32_t seg, uint32_t rough) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    seg += __shfl_xor(seg, off, 64);
+    rough += __shfl_xor(rough, off, 64);
+  }
+  if (lane == 0 && seg != 0u) {
+    atomicAdd(&fp.counters[0], static_cast<unsigned long long>(seg));
+    if (rough) atomicAdd(&fp.counters[1], static_cast<unsigned long long>(rough));
+  }
+}
+
 template <bool GEOM_LDS>
 __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_sph[];
@@ -148,101 +281,100 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
     for (uint32_t i = threadIdx.x; i < sc.n_sph; i += kBlock) lds_sph[i] = sc.sph[i];
     __syncthreads();
   }
+  const float4 *sph = GEOM_LDS ? lds_sph : sc.sph;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-  const uint32_t tx = wave % tiles_x, ty = wave / tiles_x;
-  const uint32_t x = tx * kTile + (lane & 7u);
-  const uint32_t lrow = ty * kTile + (lane >> 3);
-  const bool valid = (x < fp.width) & (lrow < fp.local_rows);
+  const uint32_t x = (wave % tiles_x) * kTile + (lane & 7u);
+  const uint32_t lrow = (wave / tiles_x) * kTile + (lane >> 3);
   uint32_t seg = 0, rough = 0;
-  if (valid) {
-    // local row -> global row of the round-robin strip partition
-    const uint32_t y = ((lrow / fp.strip_rows) * fp.world + fp.rank) * fp.strip_rows + lrow % fp.strip_rows;
-    const size_t p = static_cast<size_t>(lrow) * fp.width + x;
-    // frag.hlsl:51-57 (D14: SV_POSITION.xy = pixel centre)
-    const float pjx = (static_cast<float>(x) + 0.5f) + fp.jitter_x;
-    const float pjy = (static_cast<float>(y) + 0.5f) + fp.jitter_y;
-    const float cjx = pjx / static_cast<float>(fp.width), cjy = pjy / static_cast<float>(fp.height);
-    Rng rng{42.0f, cjx, cjy};
-    // ray.hlsl:31-37
-    f3 pw = fma3(fp.cam_right, cjx * fp.vp_width, fp.top_left);
-    pw = fma3(fp.cam_neg_up, cjy * fp.vp_height, pw);
-    f3 o = fp.cam_pos;
-    f3 d = normalize3(pw - fp.cam_pos);
-    f3 energy = mk3(1.0f, 1.0f, 1.0f);
-    f3 result = mk3(0.0f, 0.0f, 0.0f);
-    // frag.hlsl:32-46
-    for (uint32_t i = 0; i < fp.reflection_limit; ++i) {
-      const Hit h = intersect<GEOM_LDS>(sc, lds_sph, o, d);
-      if (fp.hits) fp.hits[p * fp.reflection_limit + i] = h.obj;
-      seg += 1;
-      if (h.obj < 0) {  // frag.hlsl:14-17: miss -> skybox, energy 0, loop ends (|0| < EPSILON)
-        result = fma3(energy, sample_hdri(fp, d), result);
-        break;
+  if ((x < fp.width) & (lrow < fp.local_rows)) {
+    Path s;
+    path_begin(fp, x, lrow, s);
+    if (fp.reflection_limit != 0u)
+      while (path_step(sc, sph, fp, s)) {
       }
-      const f3 pos = fma3(d, h.t, o);
-      f3 nrm;
-      if (h.plane) {
-        const float4 b = sc.pl_b[h.slot];
-        nrm = mk3(b.x, b.y, b.z);  // ray.hlsl:43-45: stored normal, not renormalised
-      } else {
-        const float4 g = GEOM_LDS ? lds_sph[h.slot] : sc.sph[h.slot];
-        nrm = normalize3(pos - mk3(g.x, g.y, g.z));
-      }
-      const float4 m0 = sc.mat0[h.obj], m1 = sc.mat1[h.obj];
-      o = fma3(nrm, 0.001f, pos);                   // frag.hlsl:21
-      const float k = 2.0f * dot3(nrm, d);          // reflect(), frag.hlsl:23
-      f3 nd = fma3(nrm, -k, d);
-      if (m0.w != 0.0f) {                           // random.hlsl:26-28
-        nd = hemisphere(fp, rng, nd, m1.w);
-        rough += 1;
-      }
-      d = nd;
-      const float cosine = saturate(dot3(nrm, d));
-      result = fma3(energy, mk3(m1.x, m1.y, m1.z), result);  // D1: energy before the update
-      energy = energy * (mk3(m0.x, m0.y, m0.z) * cosine);    // frag.hlsl:27
-      if (length3(energy) < kEpsilon) break;                  // frag.hlsl:40-42
-    }
-    // frag.hlsl:60-65 + the Rgba8UnormSrgb store (D13).  At progressive_count 0 the history
-    // weight is exactly 0, so it is not read.
-    f3 prev = mk3(0.0f, 0.0f, 0.0f);
-    if (fp.progressive_count != 0u) {
-      if (fp.accum_mode == 1) {
-        prev = mk3(fp.hist_f32[3 * p], fp.hist_f32[3 * p + 1], fp.hist_f32[3 * p + 2]);
-      } else {
-        const uint32_t w = fp.rgba8[p];
-        prev = mk3(fp.srgb_lut[w & 255u], fp.srgb_lut[(w >> 8) & 255u], fp.srgb_lut[(w >> 16) & 255u]);
-      }
-    }
-    const f3 mixed = fma3(result, fp.opacity, prev * fp.keep);
-    fp.rgba8[p] = srgb8_encode_spec(mixed.x) | (srgb8_encode_spec(mixed.y) << 8) |
-                  (srgb8_encode_spec(mixed.z) << 16) | 0xff000000u;
-    if (fp.rgbf32) {
-      fp.rgbf32[3 * p] = mixed.x;
-      fp.rgbf32[3 * p + 1] = mixed.y;
-      fp.rgbf32[3 * p + 2] = mixed.z;
-    }
-    if (fp.hist_f32 && fp.accum_mode == 1) {
-      fp.hist_f32[3 * p] = mixed.x;
-      fp.hist_f32[3 * p + 1] = mixed.y;
-      fp.hist_f32[3 * p + 2] = mixed.z;
-    }
-    if (fp.segments) fp.segments[p] = seg;
-    if (fp.hits)  // iterations that never ran are marked -2
-      for (uint32_t i = seg; i < fp.reflection_limit; ++i) fp.hits[p * fp.reflection_limit + i] = -2;
+    path_end(fp, s);
+    seg = s.seg;
+    rough = s.rough;
   }
-  // one atomic per wave for the frame totals
-  uint32_t packed_lo = seg, packed_hi = rough;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    packed_lo += __shfl_xor(packed_lo, off, 64);
-    packed_hi += __shfl_xor(packed_hi, off, 64);
+  add_totals(fp, lane, seg, rough);
+}
+
+// Resident waves + lane refill.  `refill_min`: idle lanes a wave tolerates before it pulls
+// new pixels (1 = refill at once).  fp.counters[2] is the frame's tile counter (zero at launch).
+__global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, FrameParams fp, uint32_t refill_min) {
+  extern __shared__ float4 lds_sph[];
+  for (uint32_t i = threadIdx.x; i < sc.n_sph; i += kBlock) lds_sph[i] = sc.sph[i];
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
+  const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
+  const uint32_t n_tiles = tiles_x * tiles_y;
+  unsigned int *tile_counter = reinterpret_cast<unsigned int *>(&fp.counters[2]);
+
+  Path s;
+  s.p = 0;
+  s.seg = 0;
+  s.rough = 0;
+  bool alive = false;
+  uint32_t tile = 0, tpos = 64;  // wave-uniform cursor into the current tile
+  bool work_left = true;
+  uint32_t seg_total = 0, rough_total = 0;
+
+  for (;;) {
+    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
+    const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
+    if (work_left && (n_idle >= refill_min || n_idle == 64u)) {
+      unsigned long long need = idle;
+      while (need != 0ull) {
+        if (tpos >= 64u) {  // take the next tile off the frame's work counter
+          uint32_t t = 0;
+          if (lane == 0) t = atomicAdd(tile_counter, 1u);
+          t = __builtin_amdgcn_readfirstlane(t);
+          if (t >= n_tiles) {
+            work_left = false;
+            break;
+          }
+          tile = t;
+          tpos = 0;
+        }
+        // rank of this lane among the lanes that still need a pixel
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(need >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(need), 0u));
+        const bool needy = (need >> lane) & 1ull;
+        const uint32_t k = tpos + below;
+        if (needy && k < 64u) {
+          const uint32_t x = (tile % tiles_x) * kTile + (k & 7u);
+          const uint32_t lrow = (tile / tiles_x) * kTile + (k >> 3);
+          if ((x < fp.width) & (lrow < fp.local_rows)) {
+            path_begin(fp, x, lrow, s);
+            alive = fp.reflection_limit != 0u;
+            if (!alive) path_end(fp, s);
+          }
+        }
+        const uint32_t n_need = static_cast<uint32_t>(__popcll(need));
+        const uint32_t room = 64u - tpos;
+        const uint32_t taken = n_need < room ? n_need : room;
+        tpos += taken;
+        // the `taken` lowest needy lanes are served (even if their pixel fell outside the frame)
+        need = __builtin_amdgcn_ballot_w64(needy && below >= taken);
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {
+      if (!work_left) break;
+      continue;
+    }
+    if (alive) {
+      alive = path_step(sc, lds_sph, fp, s);
+      if (!alive) {
+        path_end(fp, s);
+        seg_total += s.seg;
+        rough_total += s.rough;
+      }
+    }
   }
-  if (lane == 0 && packed_lo != 0u) {
-    atomicAdd(&fp.counters[0], static_cast<unsigned long long>(packed_lo));
-    if (packed_hi) atomicAdd(&fp.counters[1], static_cast<unsigned long long>(packed_hi));
-  }
+  add_totals(fp, lane, seg_total, rough_total);
 }
 
 __global__ void math_unary_kernel(int op, const float *x, float *y, size_t n) {
@@ -256,7 +388,8 @@ __global__ void math_unary_kernel(int op, const float *x, float *y, size_t n) {
     case 3: r = asin_spec(x[i]); break;
     case 4: r = log2_spec(x[i]); break;
     case 5: r = exp2_spec(x[i]); break;
-    default: r = sqrtf(x[i]); break;
+    case 6: r = sqrtf(x[i]); break;
+    default: r = sqrt_rn(x[i]); break;
   }
   y[i] = r;
 }
@@ -267,6 +400,17 @@ __global__ void math_binary_kernel(int op, const float *a, const float *b, float
   y[i] = op == 0 ? atan2_spec(a[i], b[i]) : (op == 1 ? pow_spec(a[i], b[i]) : a[i] / b[i]);
 }
 
+// Every non-negative float through the kernel's sqrt_rn against hipcc's correctly rounded sqrtf.
+__global__ void sqrt_exhaustive_kernel(unsigned long long *mismatches) {
+  const uint32_t stride = gridDim.x * blockDim.x;
+  uint32_t bad = 0;
+  for (uint64_t u = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u <= 0x7f800000ull; u += stride) {
+    const float x = __uint_as_float(static_cast<uint32_t>(u));
+    bad += __float_as_uint(sqrt_rn(x)) != __float_as_uint(sqrtf(x));
+  }
+  if (bad) atomicAdd(mismatches, static_cast<unsigned long long>(bad));
+}
+
 }  // namespace
 
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream) {
@@ -274,14 +418,29 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
   const uint64_t waves = static_cast<uint64_t>(tiles_x) * tiles_y;
   if (waves == 0) return 0;
-  const uint32_t blocks = static_cast<uint32_t>((waves + (kBlock / 64) - 1) / (kBlock / 64));
-  if (lc.variant == 1) {
-    hipLaunchKernelGGL(render_tiles<false>, dim3(blocks), dim3(kBlock), 0, stream, sc, fp);
+  const size_t lds = static_cast<size_t>(sc.n_sph) * sizeof(float4);
+  if (lc.variant == 2) {
+    uint32_t blocks = static_cast<uint32_t>(lc.persistent_blocks);
+    const uint64_t max_useful = (waves + (kBlock / 64) - 1) / (kBlock / 64);
+    if (blocks > max_useful) blocks = static_cast<uint32_t>(max_useful);
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(render_persistent, dim3(blocks), dim3(kBlock), lds, stream, sc, fp,
+                       static_cast<uint32_t>(lc.refill_min));
   } else {
-    const size_t lds = static_cast<size_t>(sc.n_sph) * sizeof(float4);
-    hipLaunchKernelGGL(render_tiles<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, fp);
+    const uint32_t blocks = static_cast<uint32_t>((waves + (kBlock / 64) - 1) / (kBlock / 64));
+    if (lc.variant == 1) {
+      hipLaunchKernelGGL(render_tiles<false>, dim3(blocks), dim3(kBlock), 0, stream, sc, fp);
+    } else {
+      hipLaunchKernelGGL(render_tiles<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, fp);
+    }
   }
   return static_cast<int>(hipGetLastError());
+}
+
+int persistent_blocks_per_cu(size_t lds_bytes) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_persistent, kBlock, lds_bytes) != hipSuccess) return 0;
+  return n;
 }
 
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream) {
@@ -293,6 +452,11 @@ int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t st
 int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(math_binary_kernel, dim3(static_cast<uint32_t>((n + 255) / 256)), dim3(256), 0, stream, op, a, b, y, n);
+  return static_cast<int>(hipGetLastError());
+}
+
+int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream) {
+  hipLaunchKernelGGL(sqrt_exhaustive_kernel, dim3(4096), dim3(256), 0, stream, d_mismatches);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -24,7 +24,12 @@ struct rt_context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t upload_stream = nullptr;  // rt_set_random (other thread)
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  bool owns_stream = true;
+  // Per-frame HIP-event pairs and device counters live in rings of kRing slots so the
+  // benchmark can read a whole timed region after one sync.  The ring is re-armed half a
+  // ring ahead, so the most recent kRing/2 frames are always readable.
+  static constexpr uint32_t kRing = 1024;
+  std::vector<hipEvent_t> ev_start, ev_stop;
   bool timing_valid = false;
 
   // skybox
@@ -58,9 +63,15 @@ struct rt_context {
   uint32_t *d_segments = nullptr;
   int32_t *d_hits = nullptr;
   uint32_t hits_limit = 0;  // reflection_limit the hits buffer was sized for
-  unsigned long long *d_counters = nullptr;
+  unsigned long long *d_counters = nullptr;  // kRing x {segments, rough hits, tile counter, pad}
+  // caller-owned output buffers (rt_bind_outputs); null = the context's own
+  uint32_t *ext_rgba8 = nullptr, *ext_hist_rgba8 = nullptr;
+  float *ext_rgbf32 = nullptr;
   float *d_lut = nullptr;
-  int variant = 0;
+  int variant = 2;          // RT_OPT_VARIANT
+  int refill_min = 16;      // RT_OPT_REFILL_MIN
+  int blocks_per_cu = 0;    // RT_OPT_BLOCKS_PER_CU (0 = occupancy query)
+  int cu_count = 0;
   rt_stats stats{};
   std::string error;
 };
@@ -192,13 +203,22 @@ int rt_create(int device_id, rt_context **out_ctx) {
     return code;
   };
   if (hipSetDevice(device_id) != hipSuccess) return bail(RT_ERR_NO_DEVICE);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return bail(RT_ERR_DEVICE);
+  ctx->cu_count = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(RT_ERR_DEVICE);
   if (hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(RT_ERR_DEVICE);
-  if (hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess)
-    return bail(RT_ERR_DEVICE);
+  ctx->ev_start.assign(rt_context::kRing, nullptr);
+  ctx->ev_stop.assign(rt_context::kRing, nullptr);
+  for (uint32_t i = 0; i < rt_context::kRing; ++i)
+    if (hipEventCreate(&ctx->ev_start[i]) != hipSuccess || hipEventCreate(&ctx->ev_stop[i]) != hipSuccess)
+      return bail(RT_ERR_DEVICE);
   for (int i = 0; i < 2; ++i)
     if (hipEventCreateWithFlags(&ctx->rnd_last_use[i], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
-  if (hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long)) != hipSuccess) return bail(RT_ERR_OUT_OF_MEMORY);
+  if (hipMalloc(&ctx->d_counters, rt_context::kRing * 4 * sizeof(unsigned long long)) != hipSuccess)
+    return bail(RT_ERR_OUT_OF_MEMORY);
+  if (hipMemset(ctx->d_counters, 0, rt_context::kRing * 4 * sizeof(unsigned long long)) != hipSuccess)
+    return bail(RT_ERR_DEVICE);
   if (hipMalloc(&ctx->d_lut, 256 * sizeof(float)) != hipSuccess) return bail(RT_ERR_OUT_OF_MEMORY);
   float lut[256];
   for (uint32_t b = 0; b < 256; ++b) lut[b] = srgb8_decode_spec(b);
@@ -221,9 +241,11 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_lut);
   for (int i = 0; i < 2; ++i)
     if (ctx->rnd_last_use[i]) (void)hipEventDestroy(ctx->rnd_last_use[i]);
-  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
-  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  for (hipEvent_t e : ctx->ev_start)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_stop)
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->stream && ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
   delete ctx;
   return RT_OK;
@@ -403,11 +425,39 @@ int rt_set_outputs(rt_context *ctx, uint32_t out_flags) {
   return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
 }
 
-/* Undocumented in the reference: selects the kernel variant (0 LDS-staged geometry,
- * 1 scalar-cache geometry).  Used by the benchmark to compare both. */
-int rt_set_variant(rt_context *ctx, int variant) {
+int rt_set_option(rt_context *ctx, int option, int value) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
-  ctx->variant = variant;
+  switch (option) {
+    case RT_OPT_VARIANT:
+      if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", value);
+      ctx->variant = value;
+      return RT_OK;
+    case RT_OPT_REFILL_MIN:
+      ctx->refill_min = value;
+      return RT_OK;
+    case RT_OPT_BLOCKS_PER_CU:
+      ctx->blocks_per_cu = value;
+      return RT_OK;
+    default:
+      return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
+  }
+}
+
+int rt_set_variant(rt_context *ctx, int variant) { return rt_set_option(ctx, RT_OPT_VARIANT, variant); }
+
+int rt_selftest_sqrt(rt_context *ctx, uint64_t *mismatches) {
+  if (!ctx || !mismatches) return RT_ERR_INVALID_ARGUMENT;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  unsigned long long *d = nullptr;
+  RT_HIP(ctx, hipMalloc(&d, sizeof *d));
+  hipError_t e = hipMemset(d, 0, sizeof *d);
+  const int rc = launch_sqrt_exhaustive(d, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  unsigned long long h = 0;
+  if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (rc != 0 || e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "sqrt self-test failed to run");
+  *mismatches = h;
   return RT_OK;
 }
 
@@ -457,21 +507,31 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   fp.world = ctx->world;
   fp.strip_rows = ctx->strip_rows;
   fp.local_rows = ctx->local_rows;
-  fp.rgba8 = ctx->d_rgba8;
-  fp.rgbf32 = ctx->d_rgbf32;
+  fp.rgba8 = ctx->ext_rgba8 ? ctx->ext_rgba8 : ctx->d_rgba8;
+  fp.hist_rgba8 = ctx->ext_rgba8 ? (ctx->ext_hist_rgba8 ? ctx->ext_hist_rgba8 : ctx->ext_rgba8) : ctx->d_rgba8;
+  fp.rgbf32 = ctx->ext_rgba8 ? ctx->ext_rgbf32 : ctx->d_rgbf32;
   fp.hist_f32 = ctx->d_hist_f32;
   fp.segments = ctx->d_segments;
   fp.hits = ctx->d_hits;
-  fp.counters = ctx->d_counters;
+  const uint32_t slot = static_cast<uint32_t>(ctx->stats.frames % rt_context::kRing);
+  fp.counters = ctx->d_counters + 4 * static_cast<size_t>(slot);
   fp.srgb_lut = ctx->d_lut;
   fp.accum_mode = ctx->accum_mode;
 
-  RT_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 2 * sizeof(unsigned long long), ctx->stream));
-  RT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-  LaunchConfig lc{ctx->variant};
+  if (slot % (rt_context::kRing / 2) == 0 && ctx->stats.frames != 0)  // re-arm the half we are entering
+    RT_HIP(ctx, hipMemsetAsync(ctx->d_counters + 4 * static_cast<size_t>(slot), 0,
+                               (rt_context::kRing / 2) * 4 * sizeof(unsigned long long), ctx->stream));
+  RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], ctx->stream));
+  LaunchConfig lc{};
+  lc.variant = ctx->variant;
+  lc.refill_min = ctx->refill_min < 1 ? 1 : (ctx->refill_min > 64 ? 64 : ctx->refill_min);
+  int per_cu = ctx->blocks_per_cu;
+  if (per_cu <= 0) per_cu = persistent_blocks_per_cu(static_cast<size_t>(ctx->scene.n_sph) * sizeof(float4));
+  if (per_cu <= 0) per_cu = 4;
+  lc.persistent_blocks = per_cu * ctx->cu_count;
   const int lrc = launch_render(ctx->scene, fp, lc, ctx->stream);
   if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
-  RT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], ctx->stream));
   RT_HIP(ctx, hipEventRecord(ctx->rnd_last_use[rnd], ctx->stream));
   ctx->timing_valid = true;
   ctx->stats.frames += 1;
@@ -536,12 +596,13 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->timing_valid) {
+    const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - 1) % rt_context::kRing);
     unsigned long long c[2] = {0, 0};
-    RT_HIP(ctx, hipMemcpy(c, ctx->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemcpy(c, ctx->d_counters + 4 * static_cast<size_t>(slot), sizeof c, hipMemcpyDeviceToHost));
     ctx->stats.last_segments = c[0];
     ctx->stats.last_rough_hits = c[1];
     float ms = 0.0f;
-    RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
     ctx->stats.last_kernel_ms = ms;
   }
   ctx->stats.last_pixels = static_cast<uint64_t>(ctx->local_rows) * ctx->width;
@@ -549,6 +610,42 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
   ctx->stats.height = ctx->height;
   ctx->stats.local_rows = ctx->local_rows;
   *out = ctx->stats;
+  return RT_OK;
+}
+
+int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segments, uint64_t *rough_hits, float *kernel_ms) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (n > rt_context::kRing / 2 || n > ctx->stats.frames)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_get_frame_history: %u frames asked, %llu rendered, ring keeps %u", n,
+                static_cast<unsigned long long>(ctx->stats.frames), rt_context::kRing / 2);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<unsigned long long> ring(rt_context::kRing * 4);
+  RT_HIP(ctx, hipMemcpy(ring.data(), ctx->d_counters, ring.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (uint32_t k = 0; k < n; ++k) {  // oldest first
+    const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - n + k) % rt_context::kRing);
+    if (segments) segments[k] = ring[4 * slot];
+    if (rough_hits) rough_hits[k] = ring[4 * slot + 1];
+    if (kernel_ms) RT_HIP(ctx, hipEventElapsedTime(&kernel_ms[k], ctx->ev_start[slot], ctx->ev_stop[slot]));
+  }
+  return RT_OK;
+}
+
+int rt_set_stream(rt_context *ctx, void *hip_stream) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  ctx->owns_stream = false;
+  return RT_OK;
+}
+
+int rt_bind_outputs(rt_context *ctx, void *d_rgba8, void *d_history_rgba8, void *d_rgbf32) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  ctx->ext_rgba8 = static_cast<uint32_t *>(d_rgba8);
+  ctx->ext_hist_rgba8 = static_cast<uint32_t *>(d_history_rgba8);
+  ctx->ext_rgbf32 = static_cast<float *>(d_rgbf32);
   return RT_OK;
 }
 

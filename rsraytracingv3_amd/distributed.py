@@ -1,0 +1,111 @@
+"""Tile-parallel frames over the GPUs of one node: row strips per rank + one gather.
+
+One process per GPU (``torch.distributed``; backend ``nccl`` is RCCL over xGMI on ROCm).
+The render path itself has no cross-GPU dependency — strips are independent and the
+accumulation history of a pixel stays on the rank that owns it — so the
+only collective is the gather that assembles the image on rank 0: every peer sends its
+compact strip buffer straight to the root (RCCL lowers ``gather`` to grouped
+send/recv, one xGMI link per peer), never a ring.  PyTorch is used for device memory,
+streams and the process group only.
+
+``FrameGatherer`` is backend-agnostic (gloo/CPU in the unit tests, nccl/GPU in
+production); ``TileParallelRenderer`` binds it to an rt355 ``Device``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import partition
+
+
+class FrameGatherer:
+    """Gathers per-rank compact strip buffers (padded to the largest piece) on rank 0 and
+    de-interleaves them into the (height, width[, C]) frame with one index_select."""
+
+    def __init__(self, height: int, width: int, strip_rows: int, device: torch.device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.height, self.width, self.strip_rows = height, width, strip_rows
+        self.device = device
+        self.local_rows = partition.local_row_count(height, self.rank, self.world, strip_rows)
+        self.padded_rows = partition.max_local_rows(height, self.world, strip_rows)
+        # frame row y lives at row rank(y)*padded_rows + local(y) of the stacked gather buffer
+        src = np.empty(height, np.int64)
+        for r in range(self.world):
+            idx = partition.local_row_indices(height, r, self.world, strip_rows)
+            src[idx] = r * self.padded_rows + np.arange(idx.size)
+        self.row_source = torch.from_numpy(src).to(device) if self.rank == 0 else None
+        self._stack = {}
+
+    def new_local(self, dtype=torch.int32, channels: Optional[int] = None) -> torch.Tensor:
+        """A send buffer of padded_rows x width [x channels]; the render kernel fills the first
+        local_rows rows."""
+        shape = (self.padded_rows, self.width) + ((channels,) if channels else ())
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def gather(self, local: torch.Tensor, async_op: bool = False):
+        """Collective.  Returns (stacked buffer on rank 0 | None, work handle | None)."""
+        if self.world == 1:
+            return local, None
+        key = (local.dtype, tuple(local.shape))
+        stack = None
+        if self.rank == 0:
+            stack = self._stack.get(key)
+            if stack is None:
+                stack = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=self.device)
+                self._stack[key] = stack
+        work = dist.gather(local, list(stack.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group,
+                           async_op=async_op)
+        return stack, work
+
+    def assemble(self, stacked: torch.Tensor) -> torch.Tensor:
+        """Rank 0: stacked (world, padded_rows, W[, C]) -> frame (height, W[, C])."""
+        flat = stacked.reshape((-1,) + tuple(stacked.shape[2:])) if stacked.dim() >= 3 and self.world > 1 \
+            else stacked
+        return flat.index_select(0, self.row_source)
+
+
+class TileParallelRenderer:
+    """rt355 ``Device`` + ``FrameGatherer``: renders this rank's strips on the current torch
+    stream into double-buffered send tensors and gathers the sRGB8 texels on rank 0."""
+
+    def __init__(self, rt_device, width: int, height: int, strip_rows: int = 8, group=None):
+        self.rt = rt_device
+        self.torch_device = torch.device("cuda", rt_device.device_id)
+        self.gatherer = FrameGatherer(height, width, strip_rows, self.torch_device, group)
+        g = self.gatherer
+        rt_device.set_partition(g.rank, g.world, strip_rows)
+        self.stream = torch.cuda.current_stream(self.torch_device)
+        rt_device.call("rt_set_stream", self.stream.cuda_stream)
+        self.buffers = [g.new_local(torch.int32), g.new_local(torch.int32)]
+        self.frame_index = 0
+        self.pending = None
+
+    def render(self, connection, jitter, progressive_count: int = 0, gather: bool = True, async_gather: bool = True):
+        """One frame: bind the next send buffer, launch the kernel, start the gather."""
+        buf = self.buffers[self.frame_index & 1]
+        prev = self.buffers[(self.frame_index + 1) & 1]
+        if self.pending is not None:  # the buffer we are about to overwrite was sent two frames ago
+            self.pending.wait()
+            self.pending = None
+        self.rt.call("rt_bind_outputs", buf.data_ptr(), prev.data_ptr(), None)
+        connection.frame_data.jitter = (float(jitter[0]), float(jitter[1]))
+        connection.frame_data.progressive_count = progressive_count
+        connection.draw()
+        self.frame_index += 1
+        if not gather:
+            return None
+        stacked, work = self.gatherer.gather(buf, async_op=async_gather)
+        self.pending = work
+        return stacked
+
+    def finish(self):
+        if self.pending is not None:
+            self.pending.wait()
+            self.pending = None
+        torch.cuda.current_stream(self.torch_device).synchronize()

@@ -17,11 +17,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4  # BASELINE.json north_star: per-pixel RGB within 1e-4
 
 
-def run_gpu(device, scene, size, sky, rnd, jitter, max_objects=None, frames=1, variant=0, accum=N.RT_ACCUM_SRGB8):
+def run_gpu(device, scene, size, sky, rnd, jitter, max_objects=None, frames=1, variant=2, accum=N.RT_ACCUM_SRGB8,
+            refill_min=16):
     device.set_partition(0, 1, 8)
     device.set_accum_mode(accum)
     device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32 | N.RT_OUT_SEGMENTS | N.RT_OUT_HITS)
     device.set_variant(variant)
+    device.set_option(N.RT_OPT_REFILL_MIN, refill_min)
     target = RenderTarget.new(device, size)
     rt = RandomTexture(device)
     rt.write(rnd)
@@ -59,7 +61,7 @@ def assert_frame_equal(gpu, ref):
     assert np.array_equal(rgba8, ref.rgba8)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_config1_plumbing_256(device, variant):
     """BASELINE config 1: 256x256, 4 spheres + plane, 1 bounce, reference-exact 80 slots."""
     scene = cases.config1_scene()
@@ -71,7 +73,7 @@ def test_config1_plumbing_256(device, variant):
     assert st.sphere_count == 79 and st.plane_count == 1  # 4 live + 75 zero-padded slots (D5)
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_headline_scene_small(device, variant):
     """BASELINE config 2 scene (64 spheres + plane, 8 bounces) at 320x180."""
     scene = cases.headline_scene(8)
@@ -167,6 +169,27 @@ def test_ragged_size_and_partition(device):
     assert np.array_equal(whole.view(np.uint32), ref.rgbf32.view(np.uint32))
 
 
+@pytest.mark.parametrize("refill_min", [1, 7, 64])
+def test_refill_threshold_does_not_change_results(device, refill_min):
+    """The persistent kernel hands pixels to whichever lane is free; the image must not care."""
+    scene = cases.headline_scene(8)
+    sky, rnd = cases.inputs(256, 128)
+    outs, st = run_gpu(device, scene, (203, 117), sky, rnd, (0.11, 0.37), refill_min=refill_min)
+    ref = run_oracle(scene, (203, 117), sky, rnd, (0.11, 0.37))
+    assert_frame_equal(outs[0], ref)
+    assert st.last_segments == int(ref.segments.sum())
+
+
+def test_kernel_sqrt_is_ieee_for_every_float(device):
+    """The sphere test's square root (v_sqrt_f32 + residual selection) is the correctly rounded
+    IEEE result for all 2^31 non-negative floats (compared on the device with hipcc's sqrtf,
+    which test_device_math_bitwise pins against the host's)."""
+    import ctypes as C
+    bad = C.c_uint64(123)
+    device.call("rt_selftest_sqrt", C.byref(bad))
+    assert bad.value == 0
+
+
 def test_device_math_bitwise(device):
     """The device build of every specified math function equals the oracle's, bit for bit."""
     import ctypes as C
@@ -197,6 +220,7 @@ def test_device_math_bitwise(device):
     x = np.exp(rs.uniform(-80, 80, n)).astype(np.float32)
     x[:3] = [0.0, 1e-42, 3e-39]
     assert np.array_equal(dev_unary(6, x).view(np.uint32), np.sqrt(x).view(np.uint32)), "device sqrt not IEEE"
+    assert np.array_equal(dev_unary(7, x).view(np.uint32), np.sqrt(x).view(np.uint32)), "kernel sqrt_rn not IEEE"
     a = rs.normal(size=n).astype(np.float32)
     b = rs.normal(size=n).astype(np.float32)
     a[:4], b[:4] = [0, 0, 1, -1], [0, -1, 0, 0]
