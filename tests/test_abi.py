@@ -1,0 +1,63 @@
+"""The C-ABI library loads and exports every symbol include/rt355.h declares (no compute
+calls: there is no GPU on the CPU tier)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from rsraytracingv3_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rt355.h")).read()
+    return sorted(set(re.findall(r"RT355_API\s+[\w\s\*]+?\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    names = declared_symbols()
+    for must in ("rt_create", "rt_destroy", "rt_set_skybox", "rt_set_random", "rt_set_scene", "rt_resize",
+                 "rt_render", "rt_sync", "rt_read_rgba8", "rt_read_rgbf32", "rt_last_error", "rt_get_stats",
+                 "rt_set_partition"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _native.load()
+    assert lib.rt_abi_version() == 1
+    for name in declared_symbols():
+        assert hasattr(lib, name), "librt355.so does not export %s" % name
+
+
+def test_ctypes_table_covers_the_header():
+    assert sorted(_native.SIGNATURES) == declared_symbols()
+
+
+def test_no_cxx_or_torch_types_in_the_exports():
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = [ln.split()[-1] for ln in out.splitlines() if " T " in ln]
+    assert sorted(exported) == declared_symbols()  # nothing mangled leaks out (-fvisibility=hidden)
+
+
+def test_create_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from rsraytracingv3_amd import Device
+    with pytest.raises(_native.RtError) as e:
+        Device(0)
+    assert e.value.code == -2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under rsraytracingv3_amd/ may import, link or
+    include it."""
+    pkg = os.path.join(ROOT, "rsraytracingv3_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "rt_oracle" not in text and "librt_oracle" not in text, f

@@ -1,0 +1,131 @@
+"""Host-side logic that needs no GPU: the dirty/progressive bookkeeping of
+Connection::update_buffers (connection.rs:370-410), jitter range, strip partition maths,
+synthetic input generators."""
+import numpy as np
+
+from rsraytracingv3_amd import partition, synth
+from rsraytracingv3_amd.connection import Connection, FrameData, RandomTexture
+from rsraytracingv3_amd.scene import Scene
+
+
+class FakeLib:
+    def __init__(self, log):
+        self.log = log
+
+    def rt_set_random(self, handle, w, h, ptr):
+        self.log.append(("rt_set_random", w, h))
+        return 0
+
+
+class FakeDevice:
+    """Records the C-ABI calls the host layer would make."""
+
+    def __init__(self):
+        self.log = []
+        self._lib = FakeLib(self.log)
+        self.handle = None
+        self.device_id = 0
+
+    def call(self, name, *args):
+        self.log.append((name,) + tuple(a if isinstance(a, (int, float, str)) else type(a).__name__ for a in args))
+
+
+def make_connection(max_objects=None):
+    dev = FakeDevice()
+    scene = Scene.random_spheres(3, 8, 30, 5, 3, 4)
+    conn = Connection(scene, dev, synth.procedural_skybox(16, 8), RandomTexture.start(dev), max_objects=max_objects)
+    return dev, scene, conn
+
+
+def test_update_buffers_dirty_and_progressive_count():
+    dev, scene, conn = make_connection()
+    assert [c[0] for c in dev.log] == ["rt_set_random", "rt_set_skybox"]
+    conn.update_buffers((64, 48), scene)      # last_size starts (0,0) -> dirty (connection.rs:357,373)
+    assert conn.frame_data.progressive_count == 0
+    sets = [c for c in dev.log if c[0] == "rt_set_scene"]
+    assert len(sets) == 1 and sets[0][2] == 80 and sets[0][4] == 2  # 80 object slots, 2 light slots
+    conn.update_buffers((64, 48), scene)
+    conn.update_buffers((64, 48), scene)
+    assert conn.frame_data.progressive_count == 2 and len([c for c in dev.log if c[0] == "rt_set_scene"]) == 1
+    scene.camera.fov = 60.0                   # scene != last_scene -> re-serialise, restart accumulation
+    conn.update_buffers((64, 48), scene)
+    assert conn.frame_data.progressive_count == 0 and len([c for c in dev.log if c[0] == "rt_set_scene"]) == 2
+    conn.update_buffers((32, 48), scene)      # size change -> dirty
+    assert conn.frame_data.progressive_count == 0 and len([c for c in dev.log if c[0] == "rt_set_scene"]) == 3
+
+
+def test_live_count_mode_passes_exact_count():
+    dev, scene, conn = make_connection(max_objects="live")
+    conn.update_buffers((8, 8), scene)
+    assert [c for c in dev.log if c[0] == "rt_set_scene"][0][2] == len(scene.objects)
+
+
+def test_jitter_range_and_determinism():
+    dev, scene, conn = make_connection()
+    js = []
+    for _ in range(200):
+        conn.update_buffers((8, 8), scene)
+        js.append(conn.frame_data.jitter)
+    js = np.array(js)
+    assert js.min() >= -0.495 and js.max() < 0.495   # r*0.99 - 0.495 (connection.rs:20,392-399)
+    assert js.std() > 0.2
+    _, scene2, conn2 = make_connection()
+    conn2.update_buffers((8, 8), scene2)
+    assert conn2.frame_data.jitter == tuple(js[0])
+    conn.update_buffers((8, 8), scene, jitter=(0.125, -0.25))
+    assert conn.frame_data.as_bytes()[:8] == FrameData((0.125, -0.25)).as_bytes()[:8]
+
+
+def test_partition_covers_every_row_exactly_once():
+    for height, world, strip in [(1080, 8, 8), (1080, 3, 16), (77, 3, 8), (5, 8, 8), (2160, 8, 8), (100, 1, 8)]:
+        seen = np.zeros(height, int)
+        for r in range(world):
+            idx = partition.local_row_indices(height, r, world, strip)
+            assert (np.diff(idx) > 0).all() and idx.size == partition.local_row_count(height, r, world, strip)
+            seen[idx] += 1
+        assert (seen == 1).all()
+        assert partition.max_local_rows(height, world, strip) == max(
+            partition.local_row_count(height, r, world, strip) for r in range(world))
+
+
+def test_assemble_rows_inverts_the_partition():
+    h, w, world, strip = 77, 5, 3, 8
+    full = np.arange(h * w * 2, dtype=np.float32).reshape(h, w, 2)
+    pad = partition.max_local_rows(h, world, strip)
+    pieces = []
+    for r in range(world):
+        idx = partition.local_row_indices(h, r, world, strip)
+        piece = np.full((pad, w, 2), -1, np.float32)   # padded like the gather buffers
+        piece[: idx.size] = full[idx]
+        pieces.append(piece)
+    assert np.array_equal(partition.assemble_rows(pieces, h, strip), full)
+
+
+def test_synthetic_inputs_are_reproducible_and_in_range():
+    t = synth.random_texture(5)
+    assert t.shape == (600, 600) and t.dtype == np.float32 and t.min() >= 0 and t.max() < 1
+    assert np.array_equal(t, synth.random_texture(5)) and not np.array_equal(t, synth.random_texture(6))
+    assert (t * (1 << 24) == np.floor(t * (1 << 24))).all()   # 24-bit grid like fastrand/rand f32
+    assert t.ravel()[0] == np.float32(synth.SplitMix64(5).f32())
+    sky = synth.procedural_skybox(64, 32)
+    assert sky.shape == (32, 64, 4) and (sky[..., 3] == 1).all() and sky.min() >= 0 and 20 < sky.max() < 120
+    assert sky[2, :, 2].mean() > sky[-3, :, 2].mean()   # blue sky above, dark ground below (row 0 = top)
+
+
+def test_random_scene_follows_reference_distributions():
+    s = Scene.random_spheres(3.0, 8.0, 50.0, 100, 42)
+    spheres = [o for o in s.objects if o.geometry.kind == 0]
+    assert s.objects[-1].geometry.kind == 1 and s.objects[-1].geometry.size == 100_000.0   # plane pushed last
+    assert 50 <= len(spheres) <= 100
+    for o in spheres:
+        r = o.geometry.radius
+        c = o.geometry.center
+        assert 3.0 <= r <= 8.0 and c[1] == r and np.hypot(c[0], c[2]) <= 50.0 + 1e-4
+    for i, a in enumerate(spheres):    # no overlaps (scene.rs:171-187)
+        for b in spheres[:i]:
+            d = np.linalg.norm(np.subtract(a.geometry.center, b.geometry.center))
+            assert d >= a.geometry.radius + b.geometry.radius - 1e-4
+    rough0 = np.mean([o.material.roughness == 0.0 for o in spheres])
+    emissive = np.mean([o.material.emission_strength > 0 for o in spheres])
+    assert 0.05 < rough0 < 0.45 and 0.02 < emissive < 0.4
+    assert s.camera.position == (55.0, 65.0, 55.0) and s.reflection_limit == 3
