@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--variant", type=int, default=2)
     ap.add_argument("--refill-min", type=int, default=16)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--tile-chunk", type=int, default=2)
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
@@ -88,6 +89,7 @@ def main():
     dev.set_variant(args.variant)
     dev.set_option(N.RT_OPT_REFILL_MIN, args.refill_min)
     dev.set_option(N.RT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
+    dev.set_option(N.RT_OPT_TILE_CHUNK, args.tile_chunk)
     target = RenderTarget.new(dev, (W, H))
     rt = RandomTexture(dev)
     rt.write(rnd)

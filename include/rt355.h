@@ -155,7 +155,8 @@ enum {
   RT_OPT_VARIANT = 0,      /* 0 one 8x8 tile per wave, sphere records in LDS; 1 same, records through
                               the scalar cache; 2 (default) resident waves that refill finished lanes */
   RT_OPT_REFILL_MIN = 1,   /* variant 2: idle lanes a wave tolerates before pulling pixels (1..64) */
-  RT_OPT_BLOCKS_PER_CU = 2 /* variant 2: resident workgroups per CU (0 = occupancy query)       */
+  RT_OPT_BLOCKS_PER_CU = 2,/* variant 2: resident workgroups per CU (0 = occupancy query)       */
+  RT_OPT_TILE_CHUNK = 3    /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump */
 };
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */

@@ -3,7 +3,8 @@
 // HBM layout of one context (DESIGN.md "Data layout"):
 //   compiled scene   one allocation of float4 records, re-laid out from the 112-byte AoS wire
 //                    objects (objects.rs:202-214) into what the kernel reads:
-//                      sph[n_sph]      {cx, cy, cz, r*r}        scanned by every ray segment,
+//                      sph[n_sph_pad]  {cx, cy, cz, r*r}        scanned by every ray segment (padded
+//                                                               with never-hit records),
 //                                                               staged into LDS per workgroup
 //                      sph_obj[n_sph]  original object index    (ascending; tie-break D10)
 //                      pl_a[n_pl]      {cx, cy, cz, half_size}
@@ -22,6 +23,8 @@
 
 namespace rt355 {
 
+constexpr uint32_t kSphBatch = 8;  // sphere records consumed per scan-loop trip
+
 struct DeviceScene {
   const float4 *sph;
   const int *sph_obj;
@@ -30,6 +33,7 @@ struct DeviceScene {
   const float4 *mat0;
   const float4 *mat1;
   uint32_t n_sph, n_pl, n_obj;
+  uint32_t n_sph_pad;  // records in sph[]: n_sph rounded up to kSphBatch, plus one batch of read-ahead
 };
 
 struct FrameParams {
@@ -54,7 +58,8 @@ struct FrameParams {
   float *hist_f32;  // RT_ACCUM_FLOAT32 history, else null
   uint32_t *segments;  // may be null
   int32_t *hits;       // may be null
-  unsigned long long *counters;  // [0] segments, [1] rough hits, [2] tile counter (variant 2)
+  unsigned long long *counters;  // [0] segments, [1] rough hits
+  unsigned int *tile_counters;   // variant 2: 8 work counters, 32 words (128 B) apart, zero at launch
   const float *srgb_lut;         // 256 decoded values
   int accum_mode;
 };
@@ -65,6 +70,7 @@ struct LaunchConfig {
                           // 2 persistent waves with lane refill, LDS geometry (default)
   int refill_min;         // variant 2: idle lanes tolerated before a wave pulls new pixels
   int persistent_blocks;  // variant 2: grid size (resident workgroups)
+  int tile_chunk;         // variant 2: consecutive 8x8 tiles per counter increment
 };
 int persistent_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);

@@ -21,6 +21,8 @@
 
 #include "rt_device.h"
 
+static_assert(rt355::kSphBatch == 8, "the scan loop consumes 8 sphere records per trip");
+
 namespace rt355 {
 
 namespace {
@@ -43,7 +45,10 @@ __device__ __forceinline__ float sqrt_rn(float x) {
   float r = (rd <= 0.0f) ? sd : s;
   r = (ru > 0.0f) ? su : r;
   const bool tiny = (__float_as_uint(x) - 1u) < (0x0f800000u - 1u);
-  if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) r = tiny ? sqrtf(x) : r;
+  if (__builtin_amdgcn_ballot_w64(tiny) != 0ull) {
+    asm volatile("; rare path: sqrt of a value below 2^-96" ::: "memory");  // keeps this a real branch
+    r = tiny ? sqrtf(x) : r;
+  }
   return r;
 }
 
@@ -100,45 +105,57 @@ struct Hit {
 
 // ray.hlsl:97-107 over the compiled scene.
 __device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d) {
-  float best = 1000000.0f;
+  // Closest hit as an unsigned key: for EPSILON <= t < best (both positive floats) the IEEE bit
+  // patterns order like the values, and anything else (t < EPSILON, negative, NaN from a negative
+  // discriminant) wraps to a key >= the current one.  key = bits(t) - bits(EPSILON).
+  constexpr uint32_t kEpsBits = 0x358637bdu;  // 1e-6f
+  uint32_t best_key = 0x49742400u - kEpsBits;  // 1000000.0f, the initial hit.distance (ray.hlsl:98)
   int slot = -1;
-  const uint32_t n = sc.n_sph;
-  // One sphere of ray.hlsl:53-68.  q = discriminant/4 and dn = b/2 (exact power-of-two
-  // scalings of the reference's b, c, discriminant), so t = -dn - sqrt(q) has the bits of
-  // (-b - sqrt(disc)) / (2a).  A sphere can only be accepted when q >= 0 and dn < 0 (t > 0).
+  // One sphere of ray.hlsl:53-68.  q = discriminant/4 and dn = b/2 (exact power-of-two scalings of
+  // the reference's b, c, discriminant), so t = -dn - sqrt(q) has the bits of (-b - sqrt(disc))/(2a).
+  // A sphere can only be accepted when q >= 0 and dn < 0 (then t > 0); min(q, -dn) >= 0 is a
+  // one-compare superset of that, good enough to decide whether the wave needs the root at all.
 #define RT_SPHERE_PRE(g, dn, q, cand)                                                                  \
   const float nx##dn = o.x - g.x, ny##dn = o.y - g.y, nz##dn = o.z - g.z;                              \
   const float dn = fmaf(d.z, nz##dn, fmaf(d.y, ny##dn, d.x * nx##dn));                                 \
   const float q = fmaf(dn, dn, -(fmaf(nz##dn, nz##dn, fmaf(ny##dn, ny##dn, nx##dn * nx##dn)) - g.w)); \
-  const bool cand = (q >= 0.0f) & (dn < 0.0f);
-#define RT_SPHERE_POST(idx, dn, q, cand)                  \
-  if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {        \
-    const float t = -dn - sqrt_rn(q);                     \
-    const bool acc = cand & (t >= kEpsilon) & (t < best); \
-    best = acc ? t : best;                                \
-    slot = acc ? static_cast<int>(idx) : slot;            \
+  const unsigned long long cand = __builtin_amdgcn_fcmpf(fminf(q, -dn), 0.0f, 3 /* OGE */);
+#define RT_SPHERE_POST(idx, dn, q, cand)                                     \
+  if (cand != 0ull) {                                                        \
+    const uint32_t key = __float_as_uint(-dn - sqrt_rn(q)) - kEpsBits;       \
+    slot = (key < best_key) ? static_cast<int>(idx) : slot;                  \
+    best_key = min(best_key, key);                                           \
   }
-  uint32_t i = 0;
-  for (; i + 4 <= n; i += 4) {
-    const float4 g0 = sph[i], g1 = sph[i + 1], g2 = sph[i + 2], g3 = sph[i + 3];
-    RT_SPHERE_PRE(g0, dn0, q0, c0)
-    RT_SPHERE_PRE(g1, dn1, q1, c1)
-    RT_SPHERE_PRE(g2, dn2, q2, c2)
-    RT_SPHERE_PRE(g3, dn3, q3, c3)
-    if (__builtin_amdgcn_ballot_w64(c0 | c1 | c2 | c3) != 0ull) {
-      RT_SPHERE_POST(i, dn0, q0, c0)
-      RT_SPHERE_POST(i + 1, dn1, q1, c1)
-      RT_SPHERE_POST(i + 2, dn2, q2, c2)
-      RT_SPHERE_POST(i + 3, dn3, q3, c3)
-    }
+#define RT_SPHERE_BATCH(a0, a1, a2, a3, base)                            \
+  {                                                                      \
+    RT_SPHERE_PRE(a0, dn0, q0, c0)                                       \
+    RT_SPHERE_PRE(a1, dn1, q1, c1)                                       \
+    RT_SPHERE_PRE(a2, dn2, q2, c2)                                       \
+    RT_SPHERE_PRE(a3, dn3, q3, c3)                                       \
+    if ((c0 | c1 | c2 | c3) != 0ull) {                                   \
+      RT_SPHERE_POST((base), dn0, q0, c0)                                \
+      RT_SPHERE_POST((base) + 1, dn1, q1, c1)                            \
+      RT_SPHERE_POST((base) + 2, dn2, q2, c2)                            \
+      RT_SPHERE_POST((base) + 3, dn3, q3, c3)                            \
+    }                                                                    \
   }
-  for (; i < n; ++i) {
-    const float4 g0 = sph[i];
-    RT_SPHERE_PRE(g0, dn0, q0, c0)
-    RT_SPHERE_POST(i, dn0, q0, c0)
+  // Two batches of 4 per trip, each computed while the next one's LDS reads are in flight
+  // (n_sph_pad is a multiple of 8 plus 8 readable never-hit records).
+  const uint32_t n = sc.n_sph_pad - kSphBatch;
+  float4 g0 = sph[0], g1 = sph[1], g2 = sph[2], g3 = sph[3];
+  for (uint32_t i = 0; i < n; i += 8) {
+    const float4 h0 = sph[i + 4], h1 = sph[i + 5], h2 = sph[i + 6], h3 = sph[i + 7];
+    RT_SPHERE_BATCH(g0, g1, g2, g3, i)
+    g0 = sph[i + 8];
+    g1 = sph[i + 9];
+    g2 = sph[i + 10];
+    g3 = sph[i + 11];
+    RT_SPHERE_BATCH(h0, h1, h2, h3, i + 4)
   }
+#undef RT_SPHERE_BATCH
 #undef RT_SPHERE_PRE
 #undef RT_SPHERE_POST
+  const float best = __uint_as_float(best_key + kEpsBits);
   Hit h;
   h.t = best;
   h.slot = slot;
@@ -278,7 +295,7 @@ template <bool GEOM_LDS>
 __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_sph[];
   if (GEOM_LDS) {
-    for (uint32_t i = threadIdx.x; i < sc.n_sph; i += kBlock) lds_sph[i] = sc.sph[i];
+    for (uint32_t i = threadIdx.x; i < sc.n_sph_pad; i += kBlock) lds_sph[i] = sc.sph[i];
     __syncthreads();
   }
   const float4 *sph = GEOM_LDS ? lds_sph : sc.sph;
@@ -302,16 +319,26 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
 }
 
 // Resident waves + lane refill.  `refill_min`: idle lanes a wave tolerates before it pulls
-// new pixels (1 = refill at once).  fp.counters[2] is the frame's tile counter (zero at launch).
-__global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, FrameParams fp, uint32_t refill_min) {
+// new pixels (1 = refill at once).  fp.tile_counters: 8 counters, 128 B apart, zero at launch.
+__global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, FrameParams fp, uint32_t refill_min,
+                                                            uint32_t tile_chunk) {
   extern __shared__ float4 lds_sph[];
-  for (uint32_t i = threadIdx.x; i < sc.n_sph; i += kBlock) lds_sph[i] = sc.sph[i];
+  for (uint32_t i = threadIdx.x; i < sc.n_sph_pad; i += kBlock) lds_sph[i] = sc.sph[i];
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
   const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
   const uint32_t n_tiles = tiles_x * tiles_y;
-  unsigned int *tile_counter = reinterpret_cast<unsigned int *>(&fp.counters[2]);
+  // Work distribution: the frame's tiles are cut into chunks of `tile_chunk` consecutive tiles;
+  // chunk c belongs to shard c % 8, each shard has its own counter on its own 128-byte line, a
+  // wave starts on the shard of its workgroup (workgroups are dealt round-robin over the 8 XCDs)
+  // and moves on to the next shard when its own runs dry.  One device-scope counter saturates
+  // near 90 dequeues/us (MI355X_MICROARCH.md, row "dequeue"), which a 1080p frame's 32,400
+  // tiles would hit; sharded, chunked counters do not.
+  constexpr uint32_t kShards = 8;
+  const uint32_t n_chunks = (n_tiles + tile_chunk - 1u) / tile_chunk;
+  uint32_t shard = blockIdx.x % kShards, shards_done = 0;
+  uint32_t chunk_end = 0;  // one past the last tile of the chunk in hand
 
   Path s;
   s.p = 0;
@@ -319,7 +346,7 @@ __global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, Fram
   s.rough = 0;
   bool alive = false;
   uint32_t tile = 0, tpos = 64;  // wave-uniform cursor into the current tile
-  bool work_left = true;
+  bool work_left = n_tiles != 0u;
   uint32_t seg_total = 0, rough_total = 0;
 
   for (;;) {
@@ -328,15 +355,30 @@ __global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, Fram
     if (work_left && (n_idle >= refill_min || n_idle == 64u)) {
       unsigned long long need = idle;
       while (need != 0ull) {
-        if (tpos >= 64u) {  // take the next tile off the frame's work counter
-          uint32_t t = 0;
-          if (lane == 0) t = atomicAdd(tile_counter, 1u);
-          t = __builtin_amdgcn_readfirstlane(t);
-          if (t >= n_tiles) {
-            work_left = false;
-            break;
+        if (tpos >= 64u) {  // next tile: from the chunk in hand, else a new chunk off the counters
+          if (tile + 1u < chunk_end) {
+            tile += 1u;
+          } else {
+            bool got = false;
+            while (shards_done < kShards) {
+              uint32_t t = 0;
+              if (lane == 0) t = atomicAdd(&fp.tile_counters[shard * 32u], 1u);
+              t = __builtin_amdgcn_readfirstlane(t);
+              const uint32_t c = t * kShards + shard;
+              if (c < n_chunks) {
+                tile = c * tile_chunk;
+                chunk_end = min(tile + tile_chunk, n_tiles);
+                got = true;
+                break;
+              }
+              shard = (shard + 1u) % kShards;  // this shard is exhausted for good
+              shards_done += 1u;
+            }
+            if (!got) {
+              work_left = false;
+              break;
+            }
           }
-          tile = t;
           tpos = 0;
         }
         // rank of this lane among the lanes that still need a pixel
@@ -418,14 +460,14 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
   const uint64_t waves = static_cast<uint64_t>(tiles_x) * tiles_y;
   if (waves == 0) return 0;
-  const size_t lds = static_cast<size_t>(sc.n_sph) * sizeof(float4);
+  const size_t lds = static_cast<size_t>(sc.n_sph_pad) * sizeof(float4);
   if (lc.variant == 2) {
     uint32_t blocks = static_cast<uint32_t>(lc.persistent_blocks);
     const uint64_t max_useful = (waves + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks > max_useful) blocks = static_cast<uint32_t>(max_useful);
     if (blocks == 0) blocks = 1;
     hipLaunchKernelGGL(render_persistent, dim3(blocks), dim3(kBlock), lds, stream, sc, fp,
-                       static_cast<uint32_t>(lc.refill_min));
+                       static_cast<uint32_t>(lc.refill_min), static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk));
   } else {
     const uint32_t blocks = static_cast<uint32_t>((waves + (kBlock / 64) - 1) / (kBlock / 64));
     if (lc.variant == 1) {

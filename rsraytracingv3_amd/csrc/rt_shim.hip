@@ -29,6 +29,8 @@ struct rt_context {
   // benchmark can read a whole timed region after one sync.  The ring is re-armed half a
   // ring ahead, so the most recent kRing/2 frames are always readable.
   static constexpr uint32_t kRing = 1024;
+  static constexpr uint32_t kCounterWords = 2;   // u64 words per ring slot
+  static constexpr uint32_t kTileWords = 8 * 32; // u32 words per ring slot: 8 shard counters, 128 B apart
   std::vector<hipEvent_t> ev_start, ev_stop;
   bool timing_valid = false;
 
@@ -63,7 +65,8 @@ struct rt_context {
   uint32_t *d_segments = nullptr;
   int32_t *d_hits = nullptr;
   uint32_t hits_limit = 0;  // reflection_limit the hits buffer was sized for
-  unsigned long long *d_counters = nullptr;  // kRing x {segments, rough hits, tile counter, pad}
+  unsigned long long *d_counters = nullptr;  // kRing x {segments, rough hits}
+  unsigned int *d_tile_counters = nullptr;   // kRing x kTileWords (variant 2 work counters)
   // caller-owned output buffers (rt_bind_outputs); null = the context's own
   uint32_t *ext_rgba8 = nullptr, *ext_hist_rgba8 = nullptr;
   float *ext_rgbf32 = nullptr;
@@ -72,6 +75,7 @@ struct rt_context {
   int refill_min = 16;      // RT_OPT_REFILL_MIN
   int blocks_per_cu = 0;    // RT_OPT_BLOCKS_PER_CU (0 = occupancy query)
   int cu_count = 0;
+  int tile_chunk = 2;       // RT_OPT_TILE_CHUNK
   rt_stats stats{};
   std::string error;
 };
@@ -215,9 +219,13 @@ int rt_create(int device_id, rt_context **out_ctx) {
       return bail(RT_ERR_DEVICE);
   for (int i = 0; i < 2; ++i)
     if (hipEventCreateWithFlags(&ctx->rnd_last_use[i], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
-  if (hipMalloc(&ctx->d_counters, rt_context::kRing * 4 * sizeof(unsigned long long)) != hipSuccess)
+  if (hipMalloc(&ctx->d_counters, rt_context::kRing * rt_context::kCounterWords * sizeof(unsigned long long)) != hipSuccess)
     return bail(RT_ERR_OUT_OF_MEMORY);
-  if (hipMemset(ctx->d_counters, 0, rt_context::kRing * 4 * sizeof(unsigned long long)) != hipSuccess)
+  if (hipMemset(ctx->d_counters, 0, rt_context::kRing * rt_context::kCounterWords * sizeof(unsigned long long)) != hipSuccess)
+    return bail(RT_ERR_DEVICE);
+  if (hipMalloc(&ctx->d_tile_counters, rt_context::kRing * rt_context::kTileWords * sizeof(unsigned int)) != hipSuccess)
+    return bail(RT_ERR_OUT_OF_MEMORY);
+  if (hipMemset(ctx->d_tile_counters, 0, rt_context::kRing * rt_context::kTileWords * sizeof(unsigned int)) != hipSuccess)
     return bail(RT_ERR_DEVICE);
   if (hipMalloc(&ctx->d_lut, 256 * sizeof(float)) != hipSuccess) return bail(RT_ERR_OUT_OF_MEMORY);
   float lut[256];
@@ -238,6 +246,7 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_rnd[1]);
   (void)hipFree(ctx->d_scene);
   (void)hipFree(ctx->d_counters);
+  (void)hipFree(ctx->d_tile_counters);
   (void)hipFree(ctx->d_lut);
   for (int i = 0; i < 2; ++i)
     if (ctx->rnd_last_use[i]) (void)hipEventDestroy(ctx->rnd_last_use[i]);
@@ -342,7 +351,12 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
     mat1[i] = make_float4(o.emission[0] * o.emission_strength, o.emission[1] * o.emission_strength,
                           o.emission[2] * o.emission_strength, inv_exp);
   }
-  const size_t n_sph = sph.size(), n_pl = pl_a.size();
+  const size_t n_sph_live = sph.size(), n_pl = pl_a.size();
+  // Pad the sphere records to whole scan batches plus one batch of read-ahead with records no
+  // ray can accept (r*r = -inf makes the discriminant -inf), so the scan needs no tail code.
+  const size_t n_sph = (n_sph_live + kSphBatch - 1) / kSphBatch * kSphBatch + kSphBatch;
+  sph.resize(n_sph, make_float4(0.0f, 0.0f, 0.0f, -INFINITY));
+  sph_obj.resize(n_sph, -1);
   const size_t sph_obj_rec = (n_sph + 3) / 4;  // ints packed into float4 records
   const size_t total = n_sph + sph_obj_rec + 2 * n_pl + 2 * static_cast<size_t>(object_count) + 1;
   std::vector<float4> blob(total, make_float4(0, 0, 0, 0));
@@ -380,7 +394,8 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   ctx->scene.pl_b = ctx->d_scene + off_plb;
   ctx->scene.mat0 = ctx->d_scene + off_m0;
   ctx->scene.mat1 = ctx->d_scene + off_m1;
-  ctx->scene.n_sph = static_cast<uint32_t>(n_sph);
+  ctx->scene.n_sph = static_cast<uint32_t>(n_sph_live);
+  ctx->scene.n_sph_pad = static_cast<uint32_t>(n_sph);
   ctx->scene.n_pl = static_cast<uint32_t>(n_pl);
   ctx->scene.n_obj = object_count;
   ctx->have_scene = true;
@@ -437,6 +452,9 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       return RT_OK;
     case RT_OPT_BLOCKS_PER_CU:
       ctx->blocks_per_cu = value;
+      return RT_OK;
+    case RT_OPT_TILE_CHUNK:
+      ctx->tile_chunk = value < 1 ? 1 : value;
       return RT_OK;
     default:
       return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
@@ -514,21 +532,26 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   fp.segments = ctx->d_segments;
   fp.hits = ctx->d_hits;
   const uint32_t slot = static_cast<uint32_t>(ctx->stats.frames % rt_context::kRing);
-  fp.counters = ctx->d_counters + 4 * static_cast<size_t>(slot);
+  fp.counters = ctx->d_counters + rt_context::kCounterWords * static_cast<size_t>(slot);
+  fp.tile_counters = ctx->d_tile_counters + rt_context::kTileWords * static_cast<size_t>(slot);
   fp.srgb_lut = ctx->d_lut;
   fp.accum_mode = ctx->accum_mode;
 
-  if (slot % (rt_context::kRing / 2) == 0 && ctx->stats.frames != 0)  // re-arm the half we are entering
-    RT_HIP(ctx, hipMemsetAsync(ctx->d_counters + 4 * static_cast<size_t>(slot), 0,
-                               (rt_context::kRing / 2) * 4 * sizeof(unsigned long long), ctx->stream));
+  if (slot % (rt_context::kRing / 2) == 0 && ctx->stats.frames != 0) {  // re-arm the half we are entering
+    RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counters + rt_context::kTileWords * static_cast<size_t>(slot), 0,
+                               (rt_context::kRing / 2) * rt_context::kTileWords * sizeof(unsigned int), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(ctx->d_counters + rt_context::kCounterWords * static_cast<size_t>(slot), 0,
+                               (rt_context::kRing / 2) * rt_context::kCounterWords * sizeof(unsigned long long), ctx->stream));
+  }
   RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], ctx->stream));
   LaunchConfig lc{};
   lc.variant = ctx->variant;
   lc.refill_min = ctx->refill_min < 1 ? 1 : (ctx->refill_min > 64 ? 64 : ctx->refill_min);
   int per_cu = ctx->blocks_per_cu;
-  if (per_cu <= 0) per_cu = persistent_blocks_per_cu(static_cast<size_t>(ctx->scene.n_sph) * sizeof(float4));
+  if (per_cu <= 0) per_cu = persistent_blocks_per_cu(static_cast<size_t>(ctx->scene.n_sph_pad) * sizeof(float4));
   if (per_cu <= 0) per_cu = 4;
   lc.persistent_blocks = per_cu * ctx->cu_count;
+  lc.tile_chunk = ctx->tile_chunk;
   const int lrc = launch_render(ctx->scene, fp, lc, ctx->stream);
   if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
   RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], ctx->stream));
@@ -598,7 +621,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
   if (ctx->timing_valid) {
     const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - 1) % rt_context::kRing);
     unsigned long long c[2] = {0, 0};
-    RT_HIP(ctx, hipMemcpy(c, ctx->d_counters + 4 * static_cast<size_t>(slot), sizeof c, hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemcpy(c, ctx->d_counters + rt_context::kCounterWords * static_cast<size_t>(slot), sizeof c, hipMemcpyDeviceToHost));
     ctx->stats.last_segments = c[0];
     ctx->stats.last_rough_hits = c[1];
     float ms = 0.0f;
@@ -620,12 +643,12 @@ int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segments, uint64
                 static_cast<unsigned long long>(ctx->stats.frames), rt_context::kRing / 2);
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  std::vector<unsigned long long> ring(rt_context::kRing * 4);
+  std::vector<unsigned long long> ring(rt_context::kRing * rt_context::kCounterWords);
   RT_HIP(ctx, hipMemcpy(ring.data(), ctx->d_counters, ring.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   for (uint32_t k = 0; k < n; ++k) {  // oldest first
     const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - n + k) % rt_context::kRing);
-    if (segments) segments[k] = ring[4 * slot];
-    if (rough_hits) rough_hits[k] = ring[4 * slot + 1];
+    if (segments) segments[k] = ring[rt_context::kCounterWords * slot];
+    if (rough_hits) rough_hits[k] = ring[rt_context::kCounterWords * slot + 1];
     if (kernel_ms) RT_HIP(ctx, hipEventElapsedTime(&kernel_ms[k], ctx->ev_start[slot], ctx->ev_stop[slot]));
   }
   return RT_OK;
