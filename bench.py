@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="object slots passed (0 = live count; 80 = reference padding)")
     ap.add_argument("--sky", type=int, default=2048, help="skybox width (height = width/2)")
     ap.add_argument("--variant", type=int, default=2)
-    ap.add_argument("--refill-min", type=int, default=16)
+    ap.add_argument("--refill-min", type=int, default=1)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tile-chunk", type=int, default=2)
     ap.add_argument("--strip-rows", type=int, default=8)
@@ -209,6 +209,8 @@ def main():
             "frac": round(f_alg / k_sec / 1e12 / VALU_PEAK_TFLOPS, 5),
             "alg_flops_per_launch": round(f_alg / steps, 1),
             "kernel_mrays_per_s": round(float(seg.sum()) / k_sec / 1e6, 2),
+            "scan_lane_occupancy": round(float(st.last_segments) / (64.0 * st.last_wave_iterations), 4)
+            if st.last_wave_iterations else None,
         },
     }
     if world == 1 and not args.no_cpu_baseline:

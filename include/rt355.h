@@ -65,6 +65,9 @@ typedef struct rt_stats {
   uint32_t width, height;     /* full frame                                                 */
   uint32_t local_rows;        /* rows owned by this context under the current partition     */
   uint32_t object_count, sphere_count, plane_count;
+  uint32_t _pad;
+  uint64_t last_wave_iterations; /* variant 2: object scans executed by all waves (64 lanes each);
+                                    last_segments / (64 * this) = lane occupancy of the scan */
 } rt_stats;
 
 /* Device-side view of the context's buffers, for zero-copy consumers (RCCL gather,
@@ -156,7 +159,8 @@ enum {
                               the scalar cache; 2 (default) resident waves that refill finished lanes */
   RT_OPT_REFILL_MIN = 1,   /* variant 2: idle lanes a wave tolerates before pulling pixels (1..64) */
   RT_OPT_BLOCKS_PER_CU = 2,/* variant 2: resident workgroups per CU (0 = occupancy query)       */
-  RT_OPT_TILE_CHUNK = 3    /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump */
+  RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump */
+  RT_OPT_FLAGS = 4         /* experiment switches (speed only)                                     */
 };
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */

@@ -31,7 +31,8 @@ class RtStats(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("last_segments", C.c_uint64), ("last_rough_hits", C.c_uint64),
                 ("last_pixels", C.c_uint64), ("last_kernel_ms", C.c_float), ("width", C.c_uint32),
                 ("height", C.c_uint32), ("local_rows", C.c_uint32), ("object_count", C.c_uint32),
-                ("sphere_count", C.c_uint32), ("plane_count", C.c_uint32)]
+                ("sphere_count", C.c_uint32), ("plane_count", C.c_uint32), ("_pad", C.c_uint32),
+                ("last_wave_iterations", C.c_uint64)]
 
 
 class RtDeviceBuffers(C.Structure):

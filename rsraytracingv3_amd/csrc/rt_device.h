@@ -58,7 +58,7 @@ struct FrameParams {
   float *hist_f32;  // RT_ACCUM_FLOAT32 history, else null
   uint32_t *segments;  // may be null
   int32_t *hits;       // may be null
-  unsigned long long *counters;  // [0] segments, [1] rough hits
+  unsigned long long *counters;  // [0] segments, [1] rough hits, [2] wave scan iterations (variant 2)
   unsigned int *tile_counters;   // variant 2: 8 work counters, 32 words (128 B) apart, zero at launch
   const float *srgb_lut;         // 256 decoded values
   int accum_mode;
@@ -71,6 +71,7 @@ struct LaunchConfig {
   int refill_min;         // variant 2: idle lanes tolerated before a wave pulls new pixels
   int persistent_blocks;  // variant 2: grid size (resident workgroups)
   int tile_chunk;         // variant 2: consecutive 8x8 tiles per counter increment
+  int flags;              // experiment switches (bit 0: one branch per batch of 4 spheres)
 };
 int persistent_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);

@@ -104,6 +104,7 @@ struct Hit {
 };
 
 // ray.hlsl:97-107 over the compiled scene.
+template <bool BATCH_POST>
 __device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d) {
   // Closest hit as an unsigned key: for EPSILON <= t < best (both positive floats) the IEEE bit
   // patterns order like the values, and anything else (t < EPSILON, negative, NaN from a negative
@@ -121,7 +122,7 @@ __device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *__
   const float q = fmaf(dn, dn, -(fmaf(nz##dn, nz##dn, fmaf(ny##dn, ny##dn, nx##dn * nx##dn)) - g.w)); \
   const unsigned long long cand = __builtin_amdgcn_fcmpf(fminf(q, -dn), 0.0f, 3 /* OGE */);
 #define RT_SPHERE_POST(idx, dn, q, cand)                                     \
-  if (cand != 0ull) {                                                        \
+  if (BATCH_POST || cand != 0ull) {                                          \
     const uint32_t key = __float_as_uint(-dn - sqrt_rn(q)) - kEpsBits;       \
     slot = (key < best_key) ? static_cast<int>(idx) : slot;                  \
     best_key = min(best_key, key);                                           \
@@ -213,9 +214,10 @@ __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, ui
 }
 
 // One iteration of frag.hlsl:36-43 (ray_intersect + shade).  Returns whether the loop goes on.
+template <bool BATCH_POST>
 __device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *__restrict__ sph,
                                           const FrameParams &fp, Path &s) {
-  const Hit h = intersect(sc, sph, s.o, s.d);
+  const Hit h = intersect<BATCH_POST>(sc, sph, s.o, s.d);
   if (fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
   s.seg += 1;
   if (h.obj < 0) {  // frag.hlsl:14-17: miss -> skybox, energy 0, loop ends (|0| < EPSILON)
@@ -309,7 +311,7 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
     Path s;
     path_begin(fp, x, lrow, s);
     if (fp.reflection_limit != 0u)
-      while (path_step(sc, sph, fp, s)) {
+      while (path_step<false>(sc, sph, fp, s)) {
       }
     path_end(fp, s);
     seg = s.seg;
@@ -320,6 +322,7 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
 
 // Resident waves + lane refill.  `refill_min`: idle lanes a wave tolerates before it pulls
 // new pixels (1 = refill at once).  fp.tile_counters: 8 counters, 128 B apart, zero at launch.
+template <bool BATCH_POST>
 __global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, FrameParams fp, uint32_t refill_min,
                                                             uint32_t tile_chunk) {
   extern __shared__ float4 lds_sph[];
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, Fram
   bool alive = false;
   uint32_t tile = 0, tpos = 64;  // wave-uniform cursor into the current tile
   bool work_left = n_tiles != 0u;
-  uint32_t seg_total = 0, rough_total = 0;
+  uint32_t seg_total = 0, rough_total = 0, wave_iters = 0;
 
   for (;;) {
     const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
@@ -407,8 +410,9 @@ __global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, Fram
       if (!work_left) break;
       continue;
     }
+    wave_iters += 1u;
     if (alive) {
-      alive = path_step(sc, lds_sph, fp, s);
+      alive = path_step<BATCH_POST>(sc, lds_sph, fp, s);
       if (!alive) {
         path_end(fp, s);
         seg_total += s.seg;
@@ -417,6 +421,7 @@ __global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, Fram
     }
   }
   add_totals(fp, lane, seg_total, rough_total);
+  if (lane == 0) atomicAdd(&fp.counters[2], static_cast<unsigned long long>(wave_iters));
 }
 
 __global__ void math_unary_kernel(int op, const float *x, float *y, size_t n) {
@@ -466,8 +471,13 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     const uint64_t max_useful = (waves + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks > max_useful) blocks = static_cast<uint32_t>(max_useful);
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(render_persistent, dim3(blocks), dim3(kBlock), lds, stream, sc, fp,
-                       static_cast<uint32_t>(lc.refill_min), static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk));
+    const uint32_t chunk = static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
+    if (lc.flags & 1)
+      hipLaunchKernelGGL(render_persistent<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, fp,
+                         static_cast<uint32_t>(lc.refill_min), chunk);
+    else
+      hipLaunchKernelGGL(render_persistent<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, fp,
+                         static_cast<uint32_t>(lc.refill_min), chunk);
   } else {
     const uint32_t blocks = static_cast<uint32_t>((waves + (kBlock / 64) - 1) / (kBlock / 64));
     if (lc.variant == 1) {
@@ -481,7 +491,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
 
 int persistent_blocks_per_cu(size_t lds_bytes) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_persistent, kBlock, lds_bytes) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_persistent<false>, kBlock, lds_bytes) != hipSuccess) return 0;
   return n;
 }
 

@@ -29,7 +29,7 @@ struct rt_context {
   // benchmark can read a whole timed region after one sync.  The ring is re-armed half a
   // ring ahead, so the most recent kRing/2 frames are always readable.
   static constexpr uint32_t kRing = 1024;
-  static constexpr uint32_t kCounterWords = 2;   // u64 words per ring slot
+  static constexpr uint32_t kCounterWords = 4;   // u64 words per ring slot
   static constexpr uint32_t kTileWords = 8 * 32; // u32 words per ring slot: 8 shard counters, 128 B apart
   std::vector<hipEvent_t> ev_start, ev_stop;
   bool timing_valid = false;
@@ -65,17 +65,18 @@ struct rt_context {
   uint32_t *d_segments = nullptr;
   int32_t *d_hits = nullptr;
   uint32_t hits_limit = 0;  // reflection_limit the hits buffer was sized for
-  unsigned long long *d_counters = nullptr;  // kRing x {segments, rough hits}
+  unsigned long long *d_counters = nullptr;  // kRing x {segments, rough hits, wave iterations, pad}
   unsigned int *d_tile_counters = nullptr;   // kRing x kTileWords (variant 2 work counters)
   // caller-owned output buffers (rt_bind_outputs); null = the context's own
   uint32_t *ext_rgba8 = nullptr, *ext_hist_rgba8 = nullptr;
   float *ext_rgbf32 = nullptr;
   float *d_lut = nullptr;
   int variant = 2;          // RT_OPT_VARIANT
-  int refill_min = 16;      // RT_OPT_REFILL_MIN
+  int refill_min = 1;       // RT_OPT_REFILL_MIN
   int blocks_per_cu = 0;    // RT_OPT_BLOCKS_PER_CU (0 = occupancy query)
   int cu_count = 0;
   int tile_chunk = 2;       // RT_OPT_TILE_CHUNK
+  int flags = 0;            // RT_OPT_FLAGS
   rt_stats stats{};
   std::string error;
 };
@@ -453,6 +454,9 @@ int rt_set_option(rt_context *ctx, int option, int value) {
     case RT_OPT_BLOCKS_PER_CU:
       ctx->blocks_per_cu = value;
       return RT_OK;
+    case RT_OPT_FLAGS:
+      ctx->flags = value;
+      return RT_OK;
     case RT_OPT_TILE_CHUNK:
       ctx->tile_chunk = value < 1 ? 1 : value;
       return RT_OK;
@@ -549,9 +553,10 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   lc.refill_min = ctx->refill_min < 1 ? 1 : (ctx->refill_min > 64 ? 64 : ctx->refill_min);
   int per_cu = ctx->blocks_per_cu;
   if (per_cu <= 0) per_cu = persistent_blocks_per_cu(static_cast<size_t>(ctx->scene.n_sph_pad) * sizeof(float4));
-  if (per_cu <= 0) per_cu = 4;
+  if (per_cu <= 0 || per_cu > 4) per_cu = 4;  // measured: 3-4 resident workgroups per CU is the optimum
   lc.persistent_blocks = per_cu * ctx->cu_count;
   lc.tile_chunk = ctx->tile_chunk;
+  lc.flags = ctx->flags;
   const int lrc = launch_render(ctx->scene, fp, lc, ctx->stream);
   if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
   RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], ctx->stream));
@@ -620,10 +625,11 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->timing_valid) {
     const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - 1) % rt_context::kRing);
-    unsigned long long c[2] = {0, 0};
+    unsigned long long c[3] = {0, 0, 0};
     RT_HIP(ctx, hipMemcpy(c, ctx->d_counters + rt_context::kCounterWords * static_cast<size_t>(slot), sizeof c, hipMemcpyDeviceToHost));
     ctx->stats.last_segments = c[0];
     ctx->stats.last_rough_hits = c[1];
+    ctx->stats.last_wave_iterations = c[2];
     float ms = 0.0f;
     RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
     ctx->stats.last_kernel_ms = ms;
