@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tile-chunk", type=int, default=2)
     ap.add_argument("--strip-rows", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", help="process-group backend (gloo = 1-GPU rehearsal via host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
     args = ap.parse_args()
@@ -71,10 +72,14 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if args.steps > 512:
         raise SystemExit("bench.py: --steps must be <= 512 (per-frame event ring)")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     W, H = args.width, args.height
     scene = cases.spheres_scene(args.spheres, args.bounces, seed=42, request=max(100, int(args.spheres * 1.6))) \
@@ -107,9 +112,7 @@ def main():
             conn.frame_data.progressive_count = 0
             conn.draw()
         else:
-            stacked = tiles.render(conn, jit[k], 0)
-            if rank == 0:
-                tiles.gatherer.assemble(stacked)  # the assembled frame of the previous gather
+            tiles.render(conn, jit[k], 0)  # rank 0 gets frame k-1 assembled while frame k renders
 
     def fence():
         if tiles is not None:

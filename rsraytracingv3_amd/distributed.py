@@ -41,6 +41,8 @@ class FrameGatherer:
             src[idx] = r * self.padded_rows + np.arange(idx.size)
         self.row_source = torch.from_numpy(src).to(device) if self.rank == 0 else None
         self._stack = {}
+        # rehearsal mode: a gloo group with device tensors stages the gather through host memory
+        self.via_host = (dist.is_initialized() and dist.get_backend(group) == "gloo" and device.type == "cuda")
 
     def new_local(self, dtype=torch.int32, channels: Optional[int] = None) -> torch.Tensor:
         """A send buffer of padded_rows x width [x channels]; the render kernel fills the first
@@ -52,6 +54,12 @@ class FrameGatherer:
         """Collective.  Returns (stacked buffer on rank 0 | None, work handle | None)."""
         if self.world == 1:
             return local, None
+        if self.via_host:
+            torch.cuda.current_stream(self.device).synchronize()
+            host = local.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, parts, dst=0, group=self.group)
+            return (torch.stack(parts).to(self.device) if self.rank == 0 else None), None
         key = (local.dtype, tuple(local.shape))
         stack = None
         if self.rank == 0:
@@ -72,7 +80,13 @@ class FrameGatherer:
 
 class TileParallelRenderer:
     """rt355 ``Device`` + ``FrameGatherer``: renders this rank's strips on the current torch
-    stream into double-buffered send tensors and gathers the sRGB8 texels on rank 0."""
+    stream into double-buffered send tensors and gathers the sRGB8 texels on rank 0.
+
+    Pipeline per ``render`` call k (so that gather(k-1) runs beside render(k)):
+      1. bind send buffer k%2 (free: gather(k-2) was waited for during call k-1), launch render(k);
+      2. wait for gather(k-1) and de-interleave frame k-1 on rank 0 (returned to the caller);
+      3. start gather(k) asynchronously — RCCL orders it after render(k) on the current stream.
+    ``finish`` drains the pipeline and returns the last frame."""
 
     def __init__(self, rt_device, width: int, height: int, strip_rows: int = 8, group=None):
         self.rt = rt_device
@@ -84,28 +98,34 @@ class TileParallelRenderer:
         rt_device.call("rt_set_stream", self.stream.cuda_stream)
         self.buffers = [g.new_local(torch.int32), g.new_local(torch.int32)]
         self.frame_index = 0
-        self.pending = None
+        self.pending = None  # (work handle | None, stacked buffer | None) of the gather in flight
 
-    def render(self, connection, jitter, progressive_count: int = 0, gather: bool = True, async_gather: bool = True):
-        """One frame: bind the next send buffer, launch the kernel, start the gather."""
+    def _collect(self):
+        """Wait for the gather in flight; rank 0 gets the assembled (height, width) int32 frame."""
+        if self.pending is None:
+            return None
+        work, stacked = self.pending
+        self.pending = None
+        if work is not None:
+            work.wait()
+        return self.gatherer.assemble(stacked) if self.gatherer.rank == 0 else None
+
+    def render(self, connection, jitter, progressive_count: int = 0):
+        """Launch frame k; returns frame k-1 (rank 0) or None."""
         buf = self.buffers[self.frame_index & 1]
         prev = self.buffers[(self.frame_index + 1) & 1]
-        if self.pending is not None:  # the buffer we are about to overwrite was sent two frames ago
-            self.pending.wait()
-            self.pending = None
         self.rt.call("rt_bind_outputs", buf.data_ptr(), prev.data_ptr(), None)
         connection.frame_data.jitter = (float(jitter[0]), float(jitter[1]))
         connection.frame_data.progressive_count = progressive_count
         connection.draw()
         self.frame_index += 1
-        if not gather:
-            return None
-        stacked, work = self.gatherer.gather(buf, async_op=async_gather)
-        self.pending = work
-        return stacked
+        previous_frame = self._collect()
+        stacked, work = self.gatherer.gather(buf, async_op=True)
+        self.pending = (work, stacked)
+        return previous_frame
 
     def finish(self):
-        if self.pending is not None:
-            self.pending.wait()
-            self.pending = None
+        """Drain: returns the last frame on rank 0 (None elsewhere) after a stream sync."""
+        frame = self._collect()
         torch.cuda.current_stream(self.torch_device).synchronize()
+        return frame

@@ -190,6 +190,47 @@ def test_kernel_sqrt_is_ieee_for_every_float(device):
     assert bad.value == 0
 
 
+def test_tile_parallel_renderer_single_rank(device):
+    """TileParallelRenderer without a process group: caller-owned torch send buffers
+    (rt_bind_outputs), the torch stream (rt_set_stream) and double buffering, against the oracle."""
+    import torch
+    from rsraytracingv3_amd.distributed import TileParallelRenderer
+    scene = cases.headline_scene(5)
+    sky, rnd = cases.inputs(256, 128)
+    size = (150, 93)
+    device.set_partition(0, 1, 8)
+    device.set_accum_mode(N.RT_ACCUM_SRGB8)
+    device.set_outputs(N.RT_OUT_RGBA8)
+    device.set_variant(2)
+    RenderTarget.new(device, size)
+    rt = RandomTexture(device)
+    rt.write(rnd)
+    conn = Connection(scene, device, sky, rt)
+    conn.update_buffers(size, scene, (0.0, 0.0))
+    tiles = TileParallelRenderer(device, size[0], size[1], strip_rows=8)
+    try:
+        jit = [(0.2, 0.1), (-0.4, 0.3), (0.05, -0.45)]
+        history = None
+        frames = []
+        for k, j in enumerate(jit):   # three accumulating frames through alternating buffers
+            out = tiles.render(conn, j, k)   # returns frame k-1
+            if out is not None:
+                frames.append(out.clone())
+        frames.append(tiles.finish().clone())
+        assert len(frames) == 3
+        for k, j in enumerate(jit):
+            got = frames[k].cpu().numpy().view(np.uint8).reshape(size[1], size[0], 4)
+            ref = run_oracle(scene, size, sky, rnd, j, pc=k, history=history)
+            assert np.array_equal(got, ref.rgba8), "frame %d" % k
+            history = ref.rgba8
+    finally:
+        tiles.finish()
+        device.call("rt_bind_outputs", None, None, None)
+        private = torch.cuda.Stream()   # hand the context a stream that outlives this test
+        device.call("rt_set_stream", private.cuda_stream)
+        device._keepalive_stream = private
+
+
 def test_device_math_bitwise(device):
     """The device build of every specified math function equals the oracle's, bit for bit."""
     import ctypes as C
