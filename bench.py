@@ -49,10 +49,11 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--slots", type=int, default=0, help="object slots passed (0 = live count; 80 = reference padding)")
     ap.add_argument("--sky", type=int, default=2048, help="skybox width (height = width/2)")
-    ap.add_argument("--variant", type=int, default=2)
+    ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--refill-min", type=int, default=1)
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tile-chunk", type=int, default=2)
+    ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo = 1-GPU rehearsal via host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,6 +96,7 @@ def main():
     dev.set_option(N.RT_OPT_REFILL_MIN, args.refill_min)
     dev.set_option(N.RT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
     dev.set_option(N.RT_OPT_TILE_CHUNK, args.tile_chunk)
+    dev.set_option(4, args.flags)
     target = RenderTarget.new(dev, (W, H))
     rt = RandomTexture(dev)
     rt.write(rnd)
@@ -200,7 +202,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
-            "kernel": "render_persistent" if args.variant == 2 else "render_tiles",
+            "kernel": {2: "render_persistent", 3: "render_blocks", -1: "auto (render_blocks at this size)"}.get(args.variant, "render_tiles"),
             "avg_launch_ms": round(float(kms.mean()), 5),
             "alg_bytes_per_launch": round(b_alg / steps, 1),
             "note": "VALU-bound path (SURVEY §8d): see 'valu' for the binding roofline",

@@ -155,8 +155,9 @@ RT355_API const char *rt_last_error(rt_context *ctx);
 
 /* Tuning knobs; results are bit-identical for every setting, only speed changes. */
 enum {
-  RT_OPT_VARIANT = 0,      /* 0 one 8x8 tile per wave, sphere records in LDS; 1 same, records through
-                              the scalar cache; 2 (default) resident waves that refill finished lanes */
+  RT_OPT_VARIANT = 0,      /* -1 (default) choose per launch; 0 one 8x8 tile per wave, sphere records in
+                              LDS; 1 same, records from global memory; 2 resident waves that refill
+                              finished lanes; 3 tiles whose workgroup re-packs surviving paths      */
   RT_OPT_REFILL_MIN = 1,   /* variant 2: idle lanes a wave tolerates before pulling pixels (1..64) */
   RT_OPT_BLOCKS_PER_CU = 2,/* variant 2: resident workgroups per CU (0 = occupancy query)       */
   RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump */

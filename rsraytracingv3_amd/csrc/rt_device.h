@@ -23,6 +23,8 @@
 
 namespace rt355 {
 
+constexpr uint32_t kTotalShards = 32;       // frame-total counters are sharded over this many 128 B lines
+constexpr uint32_t kTotalShardStride = 16;  // u64 words between shards (128 B)
 constexpr uint32_t kSphBatch = 8;  // sphere records consumed per scan-loop trip
 
 struct DeviceScene {
@@ -58,7 +60,8 @@ struct FrameParams {
   float *hist_f32;  // RT_ACCUM_FLOAT32 history, else null
   uint32_t *segments;  // may be null
   int32_t *hits;       // may be null
-  unsigned long long *counters;  // [0] segments, [1] rough hits, [2] wave scan iterations (variant 2)
+  unsigned long long *counters;  // kTotalShards shards, kTotalShardStride words apart, each
+                                 // {segments, rough hits, wave scan iterations (variant 2)}
   unsigned int *tile_counters;   // variant 2: 8 work counters, 32 words (128 B) apart, zero at launch
   const float *srgb_lut;         // 256 decoded values
   int accum_mode;
@@ -66,12 +69,12 @@ struct FrameParams {
 
 // kernels (rt_kernels.hip)
 struct LaunchConfig {
-  int variant;            // 0 tile kernel, LDS geometry; 1 tile kernel, scalar-cache geometry;
-                          // 2 persistent waves with lane refill, LDS geometry (default)
+  int variant;            // -1 auto; 0 tiles, LDS geometry; 1 tiles, global-memory geometry;
+                          // 2 resident waves with lane refill; 3 block-compacting tiles
   int refill_min;         // variant 2: idle lanes tolerated before a wave pulls new pixels
   int persistent_blocks;  // variant 2: grid size (resident workgroups)
   int tile_chunk;         // variant 2: consecutive 8x8 tiles per counter increment
-  int flags;              // experiment switches (bit 0: one branch per batch of 4 spheres)
+  int flags;              // reserved for experiment switches
 };
 int persistent_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);

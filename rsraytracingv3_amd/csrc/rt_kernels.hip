@@ -6,13 +6,13 @@
 // follows ray.hlsl:97-107 exactly (App. B D10: strict '<' in ascending object order ==
 // lexicographic min of (distance, index)).
 //
-// Two launch shapes share the per-segment code:
-//   render_tiles       one 8x8 pixel tile per wave, lanes idle once their path has ended
-//                      (variants 0 / 1: sphere records from LDS / through the scalar cache)
-//   render_persistent  resident waves pull 8x8 tiles from a device counter and REFILL lanes
-//                      whose path ended with the next pixels (ballot + mbcnt rank), so the
-//                      object scan keeps all 64 lanes busy although path lengths vary 1..R
-//                      (variant 2, the default)
+// Three launch shapes share the per-segment code (rt_set_option(RT_OPT_VARIANT); -1 = pick by size):
+//   render_tiles       (0 / 1) one 8x8 pixel tile per wave, lanes idle once their path has ended;
+//                      sphere records from LDS (0) or straight from global memory (1)
+//   render_persistent  (2) resident waves pull 8x8 tiles from sharded device counters and REFILL
+//                      lanes whose path ended with the next pixels (ballot + mbcnt rank)
+//   render_blocks      (3) one tile per wave, but after every bounce the workgroup packs its
+//                      surviving paths into as few waves as possible through LDS and ends the rest
 //
 // The square root of the sphere test is only evaluated when some lane of the wave can still
 // accept the sphere (ballot over "discriminant >= 0 and the sphere is in front"): lanes the
@@ -27,6 +27,12 @@ namespace rt355 {
 
 namespace {
 
+#ifndef RT_PERSISTENT_WAVES
+#define RT_PERSISTENT_WAVES 6  // waves per SIMD the persistent kernel's register budget is held to
+#endif
+#ifndef RT_BLOCKS_WAVES
+#define RT_BLOCKS_WAVES 6
+#endif
 constexpr int kBlock = 256;
 constexpr int kTile = 8;  // 8x8 pixels per tile / wave
 
@@ -104,7 +110,6 @@ struct Hit {
 };
 
 // ray.hlsl:97-107 over the compiled scene.
-template <bool BATCH_POST>
 __device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d) {
   // Closest hit as an unsigned key: for EPSILON <= t < best (both positive floats) the IEEE bit
   // patterns order like the values, and anything else (t < EPSILON, negative, NaN from a negative
@@ -122,7 +127,7 @@ __device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *__
   const float q = fmaf(dn, dn, -(fmaf(nz##dn, nz##dn, fmaf(ny##dn, ny##dn, nx##dn * nx##dn)) - g.w)); \
   const unsigned long long cand = __builtin_amdgcn_fcmpf(fminf(q, -dn), 0.0f, 3 /* OGE */);
 #define RT_SPHERE_POST(idx, dn, q, cand)                                     \
-  if (BATCH_POST || cand != 0ull) {                                          \
+  if (cand != 0ull) {                                                        \
     const uint32_t key = __float_as_uint(-dn - sqrt_rn(q)) - kEpsBits;       \
     slot = (key < best_key) ? static_cast<int>(idx) : slot;                  \
     best_key = min(best_key, key);                                           \
@@ -214,10 +219,9 @@ __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, ui
 }
 
 // One iteration of frag.hlsl:36-43 (ray_intersect + shade).  Returns whether the loop goes on.
-template <bool BATCH_POST>
 __device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *__restrict__ sph,
                                           const FrameParams &fp, Path &s) {
-  const Hit h = intersect<BATCH_POST>(sc, sph, s.o, s.d);
+  const Hit h = intersect(sc, sph, s.o, s.d);
   if (fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
   s.seg += 1;
   if (h.obj < 0) {  // frag.hlsl:14-17: miss -> skybox, energy 0, loop ends (|0| < EPSILON)
@@ -280,16 +284,28 @@ __device__ __forceinline__ void path_end(const FrameParams &fp, const Path &s) {
     for (uint32_t i = s.seg; i < fp.reflection_limit; ++i) fp.hits[p * fp.reflection_limit + i] = -2;
 }
 
-// one atomic per wave for the frame totals
-__device__ __forceinline__ void add_totals(const FrameParams &fp, uint32_t lane, uint32_t seg, uint32_t rough) {
+// Frame totals.  A workgroup reduces its four waves through LDS and issues ONE set of atomics,
+// on the totals shard of its own 128-byte line (blockIdx % kTotalShards): device-scope atomics on a
+// single line saturate near 90/us, and one set per wave on one line used to cost more than the
+// rendering itself.  The host sums the shards (rt_get_stats / rt_get_frame_history).
+__device__ __forceinline__ void add_totals(const FrameParams &fp, uint32_t seg, uint32_t rough, uint32_t iters) {
+  __shared__ unsigned int block_totals[3];
+  if (threadIdx.x < 3) block_totals[threadIdx.x] = 0;
+  __syncthreads();
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     seg += __shfl_xor(seg, off, 64);
     rough += __shfl_xor(rough, off, 64);
   }
-  if (lane == 0 && seg != 0u) {
-    atomicAdd(&fp.counters[0], static_cast<unsigned long long>(seg));
-    if (rough) atomicAdd(&fp.counters[1], static_cast<unsigned long long>(rough));
+  if ((threadIdx.x & 63u) == 0) {
+    atomicAdd(&block_totals[0], seg);
+    atomicAdd(&block_totals[1], rough);
+    atomicAdd(&block_totals[2], iters);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3 && block_totals[threadIdx.x] != 0u) {
+    unsigned long long *shard = fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride;
+    atomicAdd(&shard[threadIdx.x], static_cast<unsigned long long>(block_totals[threadIdx.x]));
   }
 }
 
@@ -311,19 +327,122 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
     Path s;
     path_begin(fp, x, lrow, s);
     if (fp.reflection_limit != 0u)
-      while (path_step<false>(sc, sph, fp, s)) {
+      while (path_step(sc, sph, fp, s)) {
       }
     path_end(fp, s);
     seg = s.seg;
     rough = s.rough;
   }
-  add_totals(fp, lane, seg, rough);
+  add_totals(fp, seg, rough, 0u);
+}
+
+// Block-compacting tile kernel.  A workgroup of NW waves starts NW 8x8 tiles (one pixel per lane).
+// After every bounce the surviving paths of the whole workgroup are counted (ballot + popcount per
+// wave, summed through LDS); as soon as they fit into fewer waves they are packed through an LDS
+// exchange buffer (64 B of path state each) into waves 0..k-1 and the surplus waves END — gfx950's
+// s_barrier drops ended waves from its count (tools/microbench/barrier_exit.hip), and their
+// registers and wave slots go to the next workgroup.  Path lengths vary 1..R, so without this most
+// of a tile's later scans run with a handful of live lanes.  Pixel results do not depend on which
+// lane finishes a path, so the frame stays bit-identical.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(DeviceScene sc, FrameParams fp) {
+  extern __shared__ float4 lds_all[];
+  __shared__ unsigned int wave_count[NW];
+  float4 *lds_sph = lds_all;
+  float4 *xchg = lds_all + sc.n_sph_pad;  // NW*64 paths x 4 float4
+  for (uint32_t i = threadIdx.x; i < sc.n_sph_pad; i += NW * 64) lds_sph[i] = sc.sph[i];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
+  const uint32_t tile = blockIdx.x * NW + wave;
+  const uint32_t x = (tile % tiles_x) * kTile + (lane & 7u);
+  const uint32_t lrow = (tile / tiles_x) * kTile + (lane >> 3);
+  Path s;
+  s.p = 0;
+  s.seg = 0;
+  s.rough = 0;
+  bool alive = false;
+  uint32_t seg_total = 0, rough_total = 0, iters = 0;
+  if ((x < fp.width) & (lrow < fp.local_rows)) {
+    path_begin(fp, x, lrow, s);
+    alive = fp.reflection_limit != 0u;
+    if (!alive) path_end(fp, s);
+  }
+  uint32_t live_waves = NW;
+  __syncthreads();  // sphere records staged
+  for (;;) {
+    if (alive) {
+      alive = path_step(sc, lds_sph, fp, s);
+      rough_total += s.rough;
+      s.rough = 0;
+      if (!alive) {
+        path_end(fp, s);
+        seg_total += s.seg;
+      }
+    }
+    iters += 1u;
+    const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
+    if (lane == 0) wave_count[wave] = static_cast<uint32_t>(__popcll(live));
+    __syncthreads();
+    uint32_t total = 0, before = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = (static_cast<uint32_t>(w) < live_waves) ? wave_count[w] : 0u;
+      before += (static_cast<uint32_t>(w) < wave) ? c : 0u;
+      total += c;
+    }
+    if (total == 0u) break;
+    const uint32_t need = (total + 63u) >> 6;
+    if (need < live_waves) {
+      // pack: path number = paths in lower waves + live lanes below this one
+      if (alive) {
+        const uint32_t r = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+        float4 *q = xchg + 4u * r;
+        q[0] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
+        q[1] = make_float4(s.d.y, s.d.z, s.energy.x, s.energy.y);
+        q[2] = make_float4(s.energy.z, s.result.x, s.result.y, s.result.z);
+        q[3] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p | (s.seg << 26)));
+      }
+      __syncthreads();
+      if (wave >= need) break;  // surplus wave: its paths now live in a lower wave
+      const uint32_t r = wave * 64u + lane;
+      alive = r < total;
+      if (alive) {
+        const float4 *q = xchg + 4u * r;
+        const float4 a = q[0], b = q[1], c = q[2], e = q[3];
+        s.o = mk3(a.x, a.y, a.z);
+        s.d = mk3(a.w, b.x, b.y);
+        s.energy = mk3(b.z, b.w, c.x);
+        s.result = mk3(c.y, c.z, c.w);
+        s.rng = Rng{e.x, e.y, e.z};
+        const uint32_t packed = __float_as_uint(e.w);
+        s.p = packed & 0x03ffffffu;
+        s.seg = packed >> 26;
+        s.rough = 0;
+      }
+      live_waves = need;
+      // No barrier here: the exchange buffer is next written after the next count barrier, which the
+      // surviving waves only pass once their reads above have completed.
+    }
+  }
+  // totals: one atomic set per wave on the workgroup's shard (waves end at different times here)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    seg_total += __shfl_xor(seg_total, off, 64);
+    rough_total += __shfl_xor(rough_total, off, 64);
+  }
+  if (lane == 0) {
+    unsigned long long *shard = fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride;
+    if (seg_total) atomicAdd(&shard[0], static_cast<unsigned long long>(seg_total));
+    if (rough_total) atomicAdd(&shard[1], static_cast<unsigned long long>(rough_total));
+    atomicAdd(&shard[2], static_cast<unsigned long long>(iters));
+  }
 }
 
 // Resident waves + lane refill.  `refill_min`: idle lanes a wave tolerates before it pulls
 // new pixels (1 = refill at once).  fp.tile_counters: 8 counters, 128 B apart, zero at launch.
-template <bool BATCH_POST>
-__global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, FrameParams fp, uint32_t refill_min,
+__global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent(DeviceScene sc, FrameParams fp, uint32_t refill_min,
                                                             uint32_t tile_chunk) {
   extern __shared__ float4 lds_sph[];
   for (uint32_t i = threadIdx.x; i < sc.n_sph_pad; i += kBlock) lds_sph[i] = sc.sph[i];
@@ -412,7 +531,7 @@ __global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, Fram
     }
     wave_iters += 1u;
     if (alive) {
-      alive = path_step<BATCH_POST>(sc, lds_sph, fp, s);
+      alive = path_step(sc, lds_sph, fp, s);
       if (!alive) {
         path_end(fp, s);
         seg_total += s.seg;
@@ -420,8 +539,7 @@ __global__ void __launch_bounds__(kBlock) render_persistent(DeviceScene sc, Fram
       }
     }
   }
-  add_totals(fp, lane, seg_total, rough_total);
-  if (lane == 0) atomicAdd(&fp.counters[2], static_cast<unsigned long long>(wave_iters));
+  add_totals(fp, seg_total, rough_total, wave_iters);
 }
 
 __global__ void math_unary_kernel(int op, const float *x, float *y, size_t n) {
@@ -463,24 +581,32 @@ __global__ void sqrt_exhaustive_kernel(unsigned long long *mismatches) {
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream) {
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
   const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
-  const uint64_t waves = static_cast<uint64_t>(tiles_x) * tiles_y;
-  if (waves == 0) return 0;
+  const uint64_t tiles = static_cast<uint64_t>(tiles_x) * tiles_y;
+  if (tiles == 0) return 0;
   const size_t lds = static_cast<size_t>(sc.n_sph_pad) * sizeof(float4);
-  if (lc.variant == 2) {
+  int variant = lc.variant;
+  if (variant < 0) {
+    // Measured on MI355X: block-compacting tiles win while a frame is a few waves
+    // per SIMD deep; resident waves with lane refill win once there is enough work to amortise their
+    // end-of-frame drain (4K frames, hundreds of spheres).
+    variant = (tiles * sc.n_sph_pad >= 6000000ull) ? 2 : 3;
+  }
+  if (variant == 3 && fp.reflection_limit > 63u) variant = 0;  // the packed path state keeps 6 bits of bounce count
+  if (variant == 2) {
     uint32_t blocks = static_cast<uint32_t>(lc.persistent_blocks);
-    const uint64_t max_useful = (waves + (kBlock / 64) - 1) / (kBlock / 64);
+    const uint64_t max_useful = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks > max_useful) blocks = static_cast<uint32_t>(max_useful);
     if (blocks == 0) blocks = 1;
     const uint32_t chunk = static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
-    if (lc.flags & 1)
-      hipLaunchKernelGGL(render_persistent<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, fp,
-                         static_cast<uint32_t>(lc.refill_min), chunk);
-    else
-      hipLaunchKernelGGL(render_persistent<false>, dim3(blocks), dim3(kBlock), lds, stream, sc, fp,
-                         static_cast<uint32_t>(lc.refill_min), chunk);
+    hipLaunchKernelGGL(render_persistent, dim3(blocks), dim3(kBlock), lds, stream, sc, fp,
+                       static_cast<uint32_t>(lc.refill_min), chunk);
+  } else if (variant == 3) {
+    const uint32_t blocks = static_cast<uint32_t>((tiles + 3) / 4);
+    const size_t bytes = lds + static_cast<size_t>(4) * 64 * 4 * sizeof(float4);
+    hipLaunchKernelGGL(render_blocks<4>, dim3(blocks), dim3(256), bytes, stream, sc, fp);
   } else {
-    const uint32_t blocks = static_cast<uint32_t>((waves + (kBlock / 64) - 1) / (kBlock / 64));
-    if (lc.variant == 1) {
+    const uint32_t blocks = static_cast<uint32_t>((tiles + (kBlock / 64) - 1) / (kBlock / 64));
+    if (variant == 1) {
       hipLaunchKernelGGL(render_tiles<false>, dim3(blocks), dim3(kBlock), 0, stream, sc, fp);
     } else {
       hipLaunchKernelGGL(render_tiles<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, fp);
@@ -491,7 +617,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
 
 int persistent_blocks_per_cu(size_t lds_bytes) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_persistent<false>, kBlock, lds_bytes) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_persistent, kBlock, lds_bytes) != hipSuccess) return 0;
   return n;
 }
 

@@ -29,7 +29,7 @@ struct rt_context {
   // benchmark can read a whole timed region after one sync.  The ring is re-armed half a
   // ring ahead, so the most recent kRing/2 frames are always readable.
   static constexpr uint32_t kRing = 1024;
-  static constexpr uint32_t kCounterWords = 4;   // u64 words per ring slot
+  static constexpr uint32_t kCounterWords = kTotalShards * kTotalShardStride;  // u64 words per ring slot
   static constexpr uint32_t kTileWords = 8 * 32; // u32 words per ring slot: 8 shard counters, 128 B apart
   std::vector<hipEvent_t> ev_start, ev_stop;
   bool timing_valid = false;
@@ -65,13 +65,13 @@ struct rt_context {
   uint32_t *d_segments = nullptr;
   int32_t *d_hits = nullptr;
   uint32_t hits_limit = 0;  // reflection_limit the hits buffer was sized for
-  unsigned long long *d_counters = nullptr;  // kRing x {segments, rough hits, wave iterations, pad}
+  unsigned long long *d_counters = nullptr;  // kRing x kTotalShards x 128 B lines of {segments, rough hits, wave iterations}
   unsigned int *d_tile_counters = nullptr;   // kRing x kTileWords (variant 2 work counters)
   // caller-owned output buffers (rt_bind_outputs); null = the context's own
   uint32_t *ext_rgba8 = nullptr, *ext_hist_rgba8 = nullptr;
   float *ext_rgbf32 = nullptr;
   float *d_lut = nullptr;
-  int variant = 2;          // RT_OPT_VARIANT
+  int variant = -1;         // RT_OPT_VARIANT (-1 = choose per launch)
   int refill_min = 1;       // RT_OPT_REFILL_MIN
   int blocks_per_cu = 0;    // RT_OPT_BLOCKS_PER_CU (0 = occupancy query)
   int cu_count = 0;
@@ -445,7 +445,7 @@ int rt_set_option(rt_context *ctx, int option, int value) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   switch (option) {
     case RT_OPT_VARIANT:
-      if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", value);
+      if (value < -1 || value > 3) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", value);
       ctx->variant = value;
       return RT_OK;
     case RT_OPT_REFILL_MIN:
@@ -553,7 +553,7 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   lc.refill_min = ctx->refill_min < 1 ? 1 : (ctx->refill_min > 64 ? 64 : ctx->refill_min);
   int per_cu = ctx->blocks_per_cu;
   if (per_cu <= 0) per_cu = persistent_blocks_per_cu(static_cast<size_t>(ctx->scene.n_sph_pad) * sizeof(float4));
-  if (per_cu <= 0 || per_cu > 4) per_cu = 4;  // measured: 3-4 resident workgroups per CU is the optimum
+  if (per_cu <= 0) per_cu = 4;
   lc.persistent_blocks = per_cu * ctx->cu_count;
   lc.tile_chunk = ctx->tile_chunk;
   lc.flags = ctx->flags;
@@ -625,8 +625,12 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->timing_valid) {
     const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - 1) % rt_context::kRing);
+    std::vector<unsigned long long> line(rt_context::kCounterWords);
+    RT_HIP(ctx, hipMemcpy(line.data(), ctx->d_counters + rt_context::kCounterWords * static_cast<size_t>(slot),
+                          line.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long c[3] = {0, 0, 0};
-    RT_HIP(ctx, hipMemcpy(c, ctx->d_counters + rt_context::kCounterWords * static_cast<size_t>(slot), sizeof c, hipMemcpyDeviceToHost));
+    for (uint32_t sh = 0; sh < kTotalShards; ++sh)
+      for (int w = 0; w < 3; ++w) c[w] += line[sh * kTotalShardStride + w];
     ctx->stats.last_segments = c[0];
     ctx->stats.last_rough_hits = c[1];
     ctx->stats.last_wave_iterations = c[2];
@@ -653,8 +657,13 @@ int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segments, uint64
   RT_HIP(ctx, hipMemcpy(ring.data(), ctx->d_counters, ring.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   for (uint32_t k = 0; k < n; ++k) {  // oldest first
     const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - n + k) % rt_context::kRing);
-    if (segments) segments[k] = ring[rt_context::kCounterWords * slot];
-    if (rough_hits) rough_hits[k] = ring[rt_context::kCounterWords * slot + 1];
+    unsigned long long c[2] = {0, 0};
+    for (uint32_t sh = 0; sh < kTotalShards; ++sh) {
+      c[0] += ring[rt_context::kCounterWords * static_cast<size_t>(slot) + sh * kTotalShardStride];
+      c[1] += ring[rt_context::kCounterWords * static_cast<size_t>(slot) + sh * kTotalShardStride + 1];
+    }
+    if (segments) segments[k] = c[0];
+    if (rough_hits) rough_hits[k] = c[1];
     if (kernel_ms) RT_HIP(ctx, hipEventElapsedTime(&kernel_ms[k], ctx->ev_start[slot], ctx->ev_stop[slot]));
   }
   return RT_OK;

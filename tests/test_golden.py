@@ -39,7 +39,7 @@ def test_hip_reproduces_golden(device, name):
     device.set_partition(0, 1, 8)
     device.set_accum_mode(N.RT_ACCUM_SRGB8)
     device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32 | N.RT_OUT_SEGMENTS)
-    device.set_variant(2)
+    device.set_variant(-1)
     target = RenderTarget.new(device, size)
     rt = RandomTexture(device)
     rt.write(rnd)

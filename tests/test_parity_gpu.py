@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4  # BASELINE.json north_star: per-pixel RGB within 1e-4
 
 
-def run_gpu(device, scene, size, sky, rnd, jitter, max_objects=None, frames=1, variant=2, accum=N.RT_ACCUM_SRGB8,
+def run_gpu(device, scene, size, sky, rnd, jitter, max_objects=None, frames=1, variant=-1, accum=N.RT_ACCUM_SRGB8,
             refill_min=16):
     device.set_partition(0, 1, 8)
     device.set_accum_mode(accum)
@@ -61,7 +61,7 @@ def assert_frame_equal(gpu, ref):
     assert np.array_equal(rgba8, ref.rgba8)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3])
 def test_config1_plumbing_256(device, variant):
     """BASELINE config 1: 256x256, 4 spheres + plane, 1 bounce, reference-exact 80 slots."""
     scene = cases.config1_scene()
@@ -73,7 +73,7 @@ def test_config1_plumbing_256(device, variant):
     assert st.sphere_count == 79 and st.plane_count == 1  # 4 live + 75 zero-padded slots (D5)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3])
 def test_headline_scene_small(device, variant):
     """BASELINE config 2 scene (64 spheres + plane, 8 bounces) at 320x180."""
     scene = cases.headline_scene(8)
@@ -133,11 +133,12 @@ def test_progressive_accumulation_float(device):
         hist = ref.rgbf32
 
 
-def test_stress_1024_spheres(device):
+@pytest.mark.parametrize("variant", [2, 3])
+def test_stress_1024_spheres(device, variant):
     """BASELINE config 3 scene (1024 spheres + plane; beyond the reference's MAX_OBJECTS)."""
     scene = cases.stress_scene(1024, 8)
     sky, rnd = cases.inputs(256, 128)
-    outs, st = run_gpu(device, scene, (160, 90), sky, rnd, (0.2, 0.3), max_objects="live")
+    outs, st = run_gpu(device, scene, (160, 90), sky, rnd, (0.2, 0.3), max_objects="live", variant=variant)
     ref = run_oracle(scene, (160, 90), sky, rnd, (0.2, 0.3), max_objects="live")
     assert st.sphere_count == 1024 and st.plane_count == 1
     assert_frame_equal(outs[0], ref)
@@ -174,7 +175,7 @@ def test_refill_threshold_does_not_change_results(device, refill_min):
     """The persistent kernel hands pixels to whichever lane is free; the image must not care."""
     scene = cases.headline_scene(8)
     sky, rnd = cases.inputs(256, 128)
-    outs, st = run_gpu(device, scene, (203, 117), sky, rnd, (0.11, 0.37), refill_min=refill_min)
+    outs, st = run_gpu(device, scene, (203, 117), sky, rnd, (0.11, 0.37), refill_min=refill_min, variant=2)
     ref = run_oracle(scene, (203, 117), sky, rnd, (0.11, 0.37))
     assert_frame_equal(outs[0], ref)
     assert st.last_segments == int(ref.segments.sum())
@@ -201,7 +202,7 @@ def test_tile_parallel_renderer_single_rank(device):
     device.set_partition(0, 1, 8)
     device.set_accum_mode(N.RT_ACCUM_SRGB8)
     device.set_outputs(N.RT_OUT_RGBA8)
-    device.set_variant(2)
+    device.set_variant(-1)
     RenderTarget.new(device, size)
     rt = RandomTexture(device)
     rt.write(rnd)
