@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt355.so")
+LIB_PATH = os.environ.get("RT355_LIB", os.path.join(_HERE, "librt355.so"))  # override: A/B of two builds
 
 RT_OK = 0
 RT_ACCUM_SRGB8, RT_ACCUM_FLOAT32 = 0, 1

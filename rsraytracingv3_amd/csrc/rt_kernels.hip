@@ -62,13 +62,18 @@ struct Rng {
   float seed, px, py;  // random.hlsl:1-2
 };
 
-// random.hlsl:4-11.  fmod(seed, 600): seed stays in [0, 1200) for texture values in [0, 1),
-// where one conditional subtraction is the exact remainder; anything else takes fmodf.
-__device__ __forceinline__ float rng_next(const FrameParams &fp, Rng &rng) {
+// random.hlsl:4-11 in two halves so the texel can be requested long before it is needed.
+// rng_texel: coord = (rng_pixel + rng_seed) % 1.0, nearest texel (both SampleLevel calls of the
+// reference address this one texel).
+__device__ __forceinline__ size_t rng_texel(const FrameParams &fp, const Rng &rng) {
   const float sx = rng.px + rng.seed, sy = rng.py + rng.seed;
   const float cx = sx - floorf(sx), cy = sy - floorf(sy);
   const uint32_t i = texel_index(cx, fp.rnd_w), j = texel_index(cy, fp.rnd_h);
-  const float x = fp.rnd[static_cast<size_t>(j) * fp.rnd_w + i];
+  return static_cast<size_t>(j) * fp.rnd_w + i;
+}
+// rng_advance: rng_seed = (rng_seed + x * 532.3412) % 600.  The seed stays in [0, 1200) for texture
+// values in [0, 1), where one conditional subtraction is the exact remainder; anything else takes fmodf.
+__device__ __forceinline__ void rng_advance(Rng &rng, float x) {
   float s = fmaf(x, 532.3412f, rng.seed);
   if (s >= 0.0f && s < 1200.0f) {
     s = (s >= 600.0f) ? s - 600.0f : s;
@@ -76,14 +81,18 @@ __device__ __forceinline__ float rng_next(const FrameParams &fp, Rng &rng) {
     s = fmodf(s, 600.0f);
   }
   rng.seed = s;
-  return x;
 }
 
-// random.hlsl:13-43 with the per-object constant 1/(phong_alpha+1) precomputed (inv_exp).
-__device__ __forceinline__ f3 hemisphere(const FrameParams &fp, Rng &rng, f3 n, float inv_exp) {
-  const float cos_theta = pow_spec(rng_next(fp, rng), inv_exp);
+// random.hlsl:13-43 with the per-object constant 1/(phong_alpha+1) precomputed (inv_exp).  x1 is the
+// first random() value, fetched by the caller before the object scan (its texel depends only on the
+// RNG state at the start of the segment).
+__device__ __forceinline__ f3 hemisphere(const FrameParams &fp, Rng &rng, f3 n, float inv_exp, float x1) {
+  rng_advance(rng, x1);
+  const float x2 = fp.rnd[rng_texel(fp, rng)];
+  rng_advance(rng, x2);
+  const float cos_theta = pow_spec(x1, inv_exp);
   const float sin_theta = sqrtf(fmaf(-cos_theta, cos_theta, 1.0f));
-  const float phi = kTwoPi * rng_next(fp, rng);
+  const float phi = kTwoPi * x2;
   float sphi, cphi;
   sincos_spec(phi, sphi, cphi);
   const float tx = cphi * sin_theta, ty = sphi * sin_theta, tz = cos_theta;
@@ -221,6 +230,9 @@ __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, ui
 // One iteration of frag.hlsl:36-43 (ray_intersect + shade).  Returns whether the loop goes on.
 __device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *__restrict__ sph,
                                           const FrameParams &fp, Path &s) {
+  // Requested now, used after the scan if the hit is rough: the gather's latency (an L2 round trip)
+  // hides under the object scan instead of heading the shading chain.
+  const float x1 = fp.rnd[rng_texel(fp, s.rng)];
   const Hit h = intersect(sc, sph, s.o, s.d);
   if (fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
   s.seg += 1;
@@ -242,7 +254,7 @@ __device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *_
   const float k = 2.0f * dot3(nrm, s.d);          // reflect(), frag.hlsl:23
   f3 nd = fma3(nrm, -k, s.d);
   if (m0.w != 0.0f) {                             // random.hlsl:26-28
-    nd = hemisphere(fp, s.rng, nd, m1.w);
+    nd = hemisphere(fp, s.rng, nd, m1.w, x1);
     s.rough += 1;
   }
   s.d = nd;
