@@ -97,6 +97,9 @@ class TileParallelRenderer:
         self.stream = torch.cuda.current_stream(self.torch_device)
         rt_device.call("rt_set_stream", self.stream.cuda_stream)
         self.buffers = [g.new_local(torch.int32), g.new_local(torch.int32)]
+        self._ptrs = [b.data_ptr() for b in self.buffers]
+        self._bind = rt_device._lib.rt_bind_outputs   # hot path: raw entry points, status checked inline
+        self._render = rt_device._lib.rt_render
         self.frame_index = 0
         self.pending = None  # (work handle | None, stacked buffer | None) of the gather in flight
 
@@ -112,12 +115,14 @@ class TileParallelRenderer:
 
     def render(self, connection, jitter, progressive_count: int = 0):
         """Launch frame k; returns frame k-1 (rank 0) or None."""
-        buf = self.buffers[self.frame_index & 1]
-        prev = self.buffers[(self.frame_index + 1) & 1]
-        self.rt.call("rt_bind_outputs", buf.data_ptr(), prev.data_ptr(), None)
+        k = self.frame_index & 1
+        buf = self.buffers[k]
+        rc = self._bind(self.rt.handle, self._ptrs[k], self._ptrs[k ^ 1], None)
+        if rc == 0:
+            rc = self._render(self.rt.handle, float(jitter[0]), float(jitter[1]), progressive_count)
+        self.rt._check(rc, "rt_render")
         connection.frame_data.jitter = (float(jitter[0]), float(jitter[1]))
         connection.frame_data.progressive_count = progressive_count
-        connection.draw()
         self.frame_index += 1
         previous_frame = self._collect()
         stacked, work = self.gatherer.gather(buf, async_op=True)
