@@ -98,6 +98,14 @@ RT355_API int rt_set_skybox(rt_context *ctx, uint32_t width, uint32_t height, co
  * every other call; a frame sees either the old or the new texture, never a mix. */
 RT355_API int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float *r32f);
 
+/* Device-side replacement of the reference's generator thread (`RandomTexture::generate_data` +
+ * `write`, random_texture.rs:67-101): fills the texture on the GPU with
+ * SplitMix64(seed) -> uniform [0,1) on the 2^-24 grid, texel k = output k+1, instead of generating on
+ * the host and uploading 1.44 MB every 4 ms.  Same thread-safety as rt_set_random. */
+RT355_API int rt_generate_random(rt_context *ctx, uint32_t width, uint32_t height, uint64_t seed);
+/* Copy the current random texture to the host (width*height floats). */
+RT355_API int rt_read_random(rt_context *ctx, float *dst, size_t bytes);
+
 /* The dirty branch of `Connection::update_buffers` (connection.rs:373-385): objects in
  * the 112-byte wire format with an EXPLICIT count (the reference derives 80 from the
  * buffer size, inputs.hlsl:77-80 — pass 80 zero-padded slots for reference-exact

@@ -48,6 +48,8 @@ SIGNATURES = {
     "rt_destroy": (_i, [_vp]),
     "rt_set_skybox": (_i, [_vp, _u32, _u32, _vp]),
     "rt_set_random": (_i, [_vp, _u32, _u32, _vp]),
+    "rt_generate_random": (_i, [_vp, _u32, _u32, C.c_uint64]),
+    "rt_read_random": (_i, [_vp, _vp, _sz]),
     "rt_set_scene": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
     "rt_resize": (_i, [_vp, _u32, _u32]),
     "rt_set_partition": (_i, [_vp, _u32, _u32, _u32]),

@@ -200,6 +200,19 @@ class RandomTexture:
         self.data = synth.random_texture(self.seed, self.WIDTH, self.HEIGHT)
         self.seed += 1
 
+    def generate_on_device(self):
+        """Same stream, generated by a kernel on the GPU (no host generation, no upload)."""
+        rc = self.device._lib.rt_generate_random(self.device.handle, self.WIDTH, self.HEIGHT, self.seed)
+        if rc != N.RT_OK:
+            raise N.RtError(rc, "rt_generate_random")
+        self.data = None
+        self.seed += 1
+
+    def read(self) -> np.ndarray:
+        out = np.empty((self.HEIGHT, self.WIDTH), np.float32)
+        self.device.call("rt_read_random", out.ctypes.data_as(C.c_void_p), out.nbytes)
+        return out
+
     def write(self, data: Optional[np.ndarray] = None):
         """random_texture.rs:78-101."""
         if data is not None:

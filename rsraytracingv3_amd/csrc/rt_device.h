@@ -78,6 +78,7 @@ struct LaunchConfig {
 };
 int persistent_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);
+int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream);
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);
 int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream);

@@ -554,6 +554,20 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
   add_totals(fp, seg_total, rough_total, wave_iters);
 }
 
+// Device-side refill of the random texture: the reference regenerates 600x600
+// uniform floats on a host thread every 4 ms and uploads them (random_texture.rs:56-75, ~360 MB/s of
+// PCIe); here texel k (row-major) is SplitMix64 output k+1 of `seed`, top 24 bits -> [0,1) on the
+// 2^-24 grid — the same stream rsraytracingv3_amd.synth.random_texture produces on the host.
+__global__ void random_fill_kernel(float *dst, uint32_t count, unsigned long long seed) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  unsigned long long z = seed + (static_cast<unsigned long long>(k) + 1ull) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  dst[k] = static_cast<float>(static_cast<uint32_t>(z >> 40)) * 5.9604644775390625e-8f;  // * 2^-24
+}
+
 __global__ void math_unary_kernel(int op, const float *x, float *y, size_t n) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -631,6 +645,12 @@ int persistent_blocks_per_cu(size_t lds_bytes) {
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_persistent, kBlock, lds_bytes) != hipSuccess) return 0;
   return n;
+}
+
+int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream) {
+  if (count == 0) return 0;
+  hipLaunchKernelGGL(random_fill_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, dst, count, seed);
+  return static_cast<int>(hipGetLastError());
 }
 
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream) {

@@ -287,14 +287,15 @@ int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float 
   // the old copy; one that used the target copy earlier is waited for on the upload stream.
   int target;
   bool wait_use;
+  const size_t bytes = static_cast<size_t>(width) * height * 4;
   {
+    // under the lock: a frame that chose `target` earlier has its last-use event recorded by now
     std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
     target = (ctx->rnd_cur == 0) ? 1 : 0;
     wait_use = ctx->rnd_used[target];
+    if (wait_use && hipStreamWaitEvent(ctx->upload_stream, ctx->rnd_last_use[target], 0) != hipSuccess)
+      return RT_ERR_DEVICE;
   }
-  const size_t bytes = static_cast<size_t>(width) * height * 4;
-  if (wait_use && hipStreamWaitEvent(ctx->upload_stream, ctx->rnd_last_use[target], 0) != hipSuccess)
-    return RT_ERR_DEVICE;
   if (ctx->rnd_cap[target] < bytes) {
     if (hipStreamSynchronize(ctx->upload_stream) != hipSuccess) return RT_ERR_DEVICE;
     if (wait_use && hipEventSynchronize(ctx->rnd_last_use[target]) != hipSuccess) return RT_ERR_DEVICE;
@@ -313,6 +314,60 @@ int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float 
     ctx->rnd_h[target] = height;
     ctx->rnd_cur = target;
   }
+  return RT_OK;
+}
+
+int rt_generate_random(rt_context *ctx, uint32_t width, uint32_t height, uint64_t seed) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!width || !height) return RT_ERR_INVALID_ARGUMENT;
+  if (hipSetDevice(ctx->device) != hipSuccess) return RT_ERR_DEVICE;
+  // same double-buffer protocol as rt_set_random, filled by a kernel instead of a host copy
+  int target;
+  bool wait_use;
+  const size_t bytes = static_cast<size_t>(width) * height * 4;
+  {
+    // under the lock: a frame that chose `target` earlier has its last-use event recorded by now
+    std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
+    target = (ctx->rnd_cur == 0) ? 1 : 0;
+    wait_use = ctx->rnd_used[target];
+    if (wait_use && hipStreamWaitEvent(ctx->upload_stream, ctx->rnd_last_use[target], 0) != hipSuccess)
+      return RT_ERR_DEVICE;
+  }
+  if (ctx->rnd_cap[target] < bytes) {
+    if (hipStreamSynchronize(ctx->upload_stream) != hipSuccess) return RT_ERR_DEVICE;
+    if (wait_use && hipEventSynchronize(ctx->rnd_last_use[target]) != hipSuccess) return RT_ERR_DEVICE;
+    (void)hipFree(ctx->d_rnd[target]);
+    ctx->d_rnd[target] = nullptr;
+    ctx->rnd_cap[target] = 0;
+    if (hipMalloc(&ctx->d_rnd[target], bytes) != hipSuccess) return RT_ERR_OUT_OF_MEMORY;
+    ctx->rnd_cap[target] = bytes;
+  }
+  if (launch_random_fill(ctx->d_rnd[target], width * height, seed, ctx->upload_stream) != 0) return RT_ERR_DEVICE;
+  if (hipStreamSynchronize(ctx->upload_stream) != hipSuccess) return RT_ERR_DEVICE;
+  {
+    std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
+    ctx->rnd_w[target] = width;
+    ctx->rnd_h[target] = height;
+    ctx->rnd_cur = target;
+  }
+  return RT_OK;
+}
+
+int rt_read_random(rt_context *ctx, float *dst, size_t bytes) {
+  if (!ctx || !dst) return RT_ERR_INVALID_ARGUMENT;
+  int cur;
+  uint32_t w, h;
+  {
+    std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
+    cur = ctx->rnd_cur;
+    w = cur >= 0 ? ctx->rnd_w[cur] : 0;
+    h = cur >= 0 ? ctx->rnd_h[cur] : 0;
+  }
+  if (cur < 0) return fail(ctx, RT_ERR_NOT_READY, "rt_read_random: no random texture");
+  if (bytes != static_cast<size_t>(w) * h * 4)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_read_random: %zu bytes given, %zu expected", bytes, static_cast<size_t>(w) * h * 4);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipMemcpy(dst, ctx->d_rnd[cur], bytes, hipMemcpyDeviceToHost));
   return RT_OK;
 }
 
@@ -496,16 +551,15 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   if (rc != RT_OK) return rc;
 
   FrameParams fp{};
-  int rnd;
-  {
-    std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
-    rnd = ctx->rnd_cur;
-    if (rnd >= 0) {
-      fp.rnd = ctx->d_rnd[rnd];
-      fp.rnd_w = ctx->rnd_w[rnd];
-      fp.rnd_h = ctx->rnd_h[rnd];
-      ctx->rnd_used[rnd] = true;
-    }
+  // The random-texture copy this frame reads is chosen, the kernel launched and the copy's
+  // "last use" event recorded under one lock: rt_set_random (other thread) waits on that event
+  // before it refills the copy, so it must never observe the choice without the event.
+  std::unique_lock<std::mutex> rnd_lock(ctx->rnd_mutex);
+  const int rnd = ctx->rnd_cur;
+  if (rnd >= 0) {
+    fp.rnd = ctx->d_rnd[rnd];
+    fp.rnd_w = ctx->rnd_w[rnd];
+    fp.rnd_h = ctx->rnd_h[rnd];
   }
   if (rnd < 0) return fail(ctx, RT_ERR_NOT_READY, "rt_render: no random texture (rt_set_random)");
   fp.width = ctx->width;
@@ -561,6 +615,8 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
   RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], ctx->stream));
   RT_HIP(ctx, hipEventRecord(ctx->rnd_last_use[rnd], ctx->stream));
+  ctx->rnd_used[rnd] = true;
+  rnd_lock.unlock();
   ctx->timing_valid = true;
   ctx->stats.frames += 1;
   return RT_OK;
