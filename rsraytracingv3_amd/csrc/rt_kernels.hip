@@ -118,13 +118,20 @@ struct Hit {
   bool plane;
 };
 
-// ray.hlsl:97-107 over the compiled scene.
-__device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d) {
-  // Closest hit as an unsigned key: for EPSILON <= t < best (both positive floats) the IEEE bit
-  // patterns order like the values, and anything else (t < EPSILON, negative, NaN from a negative
-  // discriminant) wraps to a key >= the current one.  key = bits(t) - bits(EPSILON).
-  constexpr uint32_t kEpsBits = 0x358637bdu;  // 1e-6f
-  uint32_t best_key = 0x49742400u - kEpsBits;  // 1000000.0f, the initial hit.distance (ray.hlsl:98)
+// Closest sphere hit as an unsigned key: for EPSILON <= t < best (both positive floats) the IEEE bit
+// patterns order like the values, and anything else (t < EPSILON, negative, NaN from a negative
+// discriminant) wraps to a key >= the current one.  key = bits(t) - bits(EPSILON).
+constexpr uint32_t kEpsBits = 0x358637bdu;              // 1e-6f
+constexpr uint32_t kNoHitKey = 0x49742400u - kEpsBits;  // 1000000.0f, the initial hit.distance (ray.hlsl:98)
+
+struct SphereHit {
+  uint32_t key;  // bits(t) - bits(EPSILON), kNoHitKey = none
+  int slot;      // sphere slot, -1 = none
+};
+
+// The sphere part of ray.hlsl:97-107, one ray per lane (call with the lanes that carry a ray).
+__device__ __forceinline__ SphereHit scan_spheres(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d) {
+  uint32_t best_key = kNoHitKey;
   int slot = -1;
   // One sphere of ray.hlsl:53-68.  q = discriminant/4 and dn = b/2 (exact power-of-two scalings of
   // the reference's b, c, discriminant), so t = -dn - sqrt(q) has the bits of (-b - sqrt(disc))/(2a).
@@ -170,13 +177,84 @@ __device__ __forceinline__ Hit intersect(const DeviceScene &sc, const float4 *__
 #undef RT_SPHERE_BATCH
 #undef RT_SPHERE_PRE
 #undef RT_SPHERE_POST
-  const float best = __uint_as_float(best_key + kEpsBits);
+  return SphereHit{best_key, slot};
+}
+
+// Wave-cooperative sphere scan for waves with few live rays (<= 16 of 64 lanes): G = 4, 8 or 16
+// lanes work for one ray, each testing every G-th sphere, and the closest hit is selected across the
+// G lanes with wavefront cross-lane operations — a lexicographic (key, slot) min over xor-butterfly
+// partners, which is exactly the reference's "strict '<' in ascending index" rule (App. B D10).
+// Rays are handed to lane groups and results handed back with ds_permute/ds_bpermute; every lane of
+// the wave must call this (full EXEC), `alive` says which lanes own a ray.  A 16-ray wave costs 18
+// sphere steps instead of 72.
+__device__ __forceinline__ SphereHit scan_spheres_coop(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d,
+                                                       bool alive, unsigned long long live, uint32_t n_live_rays) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t shift = n_live_rays <= 4u ? 4u : (n_live_rays <= 8u ? 3u : 2u);  // log2(G), wave-uniform
+  const uint32_t G = 1u << shift;
+  // rank of each live lane among the live lanes; dead lanes get the ranks after them, so that
+  // "rank -> lane" is a permutation of 0..63 and ds_permute never collides
+  const unsigned long long dead = ~live;
+  const uint32_t live_below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+  const uint32_t dead_below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(dead >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(dead), 0u));
+  const uint32_t rank = alive ? live_below : n_live_rays + dead_below;
+  const int owner = __builtin_amdgcn_ds_permute(static_cast<int>(rank << 2), static_cast<int>(lane));  // lane k: owner of ray k
+  const uint32_t ray = lane >> shift;       // the ray this lane works for
+  const uint32_t sub = lane & (G - 1u);     // its share of the spheres: sub, sub+G, ...
+  const bool has_ray = ray < n_live_rays;
+  const int src = __builtin_amdgcn_ds_bpermute(static_cast<int>(ray << 2), owner) << 2;
+  f3 ro, rd;
+  ro.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o.x)));
+  ro.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o.y)));
+  ro.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(o.z)));
+  rd.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.x)));
+  rd.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.y)));
+  rd.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.z)));
+  uint32_t key = kNoHitKey;
+  int slot = -1;
+  const uint32_t n = sc.n_sph_pad - kSphBatch;  // records that can hit (the tail records never do)
+  for (uint32_t base = 0; base < n; base += G) {
+    const uint32_t j = base + sub;             // < n_sph_pad: n is a multiple of 8 and 8 more are readable
+    const float4 g = sph[j];
+    const float nx = ro.x - g.x, ny = ro.y - g.y, nz = ro.z - g.z;
+    const float dn = fmaf(rd.z, nz, fmaf(rd.y, ny, rd.x * nx));
+    const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
+    const unsigned long long cand = __builtin_amdgcn_fcmpf(has_ray ? fminf(q, -dn) : -1.0f, 0.0f, 3 /* OGE */);
+    if (cand != 0ull) {
+      const uint32_t k = __float_as_uint(-dn - sqrt_rn(q)) - kEpsBits;
+      const bool take = has_ray & (k < key);
+      slot = take ? static_cast<int>(j) : slot;
+      key = take ? k : key;
+    }
+  }
+  // closest hit across the G lanes of a ray: lexicographic min of (key, slot)
+  for (uint32_t off = 1; off < G; off <<= 1) {
+    const uint32_t ok = static_cast<uint32_t>(__shfl_xor(static_cast<int>(key), static_cast<int>(off), 64));
+    const int os = __shfl_xor(slot, static_cast<int>(off), 64);
+    const bool take = (ok < key) | ((ok == key) & (os < slot));
+    key = take ? ok : key;
+    slot = take ? os : slot;
+  }
+  // back to the lane that owns the ray: the first lane of group `live_below`
+  const int back = static_cast<int>((live_below << shift) << 2);
+  SphereHit h;
+  h.key = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(back, static_cast<int>(key)));
+  h.slot = __builtin_amdgcn_ds_bpermute(back, slot);
+  return h;
+}
+
+// The rest of ray.hlsl:97-107: sphere result -> Hit, then the planes (ray.hlsl:69-94).
+__device__ __forceinline__ Hit finish_hit(const DeviceScene &sc, SphereHit sh, f3 o, f3 d) {
+  const float best = __uint_as_float(sh.key + kEpsBits);
+  const int slot = sh.slot;
   Hit h;
   h.t = best;
   h.slot = slot;
   h.plane = false;
   h.obj = (slot >= 0) ? sc.sph_obj[slot] : -1;
-  for (uint32_t j = 0; j < sc.n_pl; ++j) {  // ray.hlsl:69-94
+  for (uint32_t j = 0; j < sc.n_pl; ++j) {
     const float4 a = sc.pl_a[j], b = sc.pl_b[j];
     const f3 c = mk3(a.x, a.y, a.z), nrm = mk3(b.x, b.y, b.z);
     const int idx = static_cast<int>(f2u(b.w));
@@ -227,13 +305,10 @@ __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, ui
   s.rough = 0;
 }
 
-// One iteration of frag.hlsl:36-43 (ray_intersect + shade).  Returns whether the loop goes on.
-__device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *__restrict__ sph,
-                                          const FrameParams &fp, Path &s) {
-  // Requested now, used after the scan if the hit is rough: the gather's latency (an L2 round trip)
-  // hides under the object scan instead of heading the shading chain.
-  const float x1 = fp.rnd[rng_texel(fp, s.rng)];
-  const Hit h = intersect(sc, sph, s.o, s.d);
+// shade() of one iteration of frag.hlsl:36-43 for the hit `h`; x1 is the first random() texel value,
+// requested before the scan.  Returns whether the loop goes on.
+__device__ __forceinline__ bool path_shade(const DeviceScene &sc, const float4 *__restrict__ sph,
+                                           const FrameParams &fp, Path &s, const Hit h, const float x1) {
   if (fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
   s.seg += 1;
   if (h.obj < 0) {  // frag.hlsl:14-17: miss -> skybox, energy 0, loop ends (|0| < EPSILON)
@@ -263,6 +338,34 @@ __device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *_
   s.energy = s.energy * (mk3(m0.x, m0.y, m0.z) * cosine);      // frag.hlsl:27
   if (length3(s.energy) < kEpsilon) return false;              // frag.hlsl:40-42
   return s.seg < fp.reflection_limit;
+}
+
+// One iteration of frag.hlsl:36-43 (ray_intersect + shade) for the calling lanes (one ray each).
+__device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *__restrict__ sph,
+                                          const FrameParams &fp, Path &s) {
+  // Requested now, used after the scan if the hit is rough: the gather's latency (an L2 round trip)
+  // hides under the object scan instead of heading the shading chain.
+  const float x1 = fp.rnd[rng_texel(fp, s.rng)];
+  const Hit h = finish_hit(sc, scan_spheres(sc, sph, s.o, s.d), s.o, s.d);
+  return path_shade(sc, sph, fp, s, h, x1);
+}
+
+// The same for a whole wave (every lane calls it; `alive` = this lane carries a ray): picks the
+// wave-cooperative scan when at most 16 lanes are live.  Returns the lane's new `alive`.
+__device__ __forceinline__ bool path_step_wave(const DeviceScene &sc, const float4 *__restrict__ sph,
+                                               const FrameParams &fp, Path &s, bool alive) {
+  const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
+  const uint32_t n_live = static_cast<uint32_t>(__popcll(live));
+  if (n_live == 0u) return false;
+  if (n_live <= 16u) {
+    float x1 = 0.0f;
+    if (alive) x1 = fp.rnd[rng_texel(fp, s.rng)];
+    const SphereHit sh = scan_spheres_coop(sc, sph, s.o, s.d, alive, live, n_live);
+    if (alive) alive = path_shade(sc, sph, fp, s, finish_hit(sc, sh, s.o, s.d), x1);
+  } else if (alive) {
+    alive = path_step(sc, sph, fp, s);
+  }
+  return alive;
 }
 
 // frag.hlsl:60-65 + the Rgba8UnormSrgb store (D13).  At progressive_count 0 the history weight
@@ -335,12 +438,20 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
   const uint32_t x = (wave % tiles_x) * kTile + (lane & 7u);
   const uint32_t lrow = (wave / tiles_x) * kTile + (lane >> 3);
   uint32_t seg = 0, rough = 0;
-  if ((x < fp.width) & (lrow < fp.local_rows)) {
-    Path s;
+  Path s;
+  s.p = 0;
+  s.seg = 0;
+  s.rough = 0;
+  s.o = s.d = s.energy = s.result = mk3(0.0f, 0.0f, 0.0f);
+  s.rng = Rng{0.0f, 0.0f, 0.0f};
+  const bool valid = (x < fp.width) & (lrow < fp.local_rows);
+  bool alive = false;
+  if (valid) {
     path_begin(fp, x, lrow, s);
-    if (fp.reflection_limit != 0u)
-      while (path_step(sc, sph, fp, s)) {
-      }
+    alive = fp.reflection_limit != 0u;
+  }
+  while (__builtin_amdgcn_ballot_w64(alive) != 0ull) alive = path_step_wave(sc, sph, fp, s, alive);
+  if (valid) {
     path_end(fp, s);
     seg = s.seg;
     rough = s.rough;
@@ -373,6 +484,8 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   s.p = 0;
   s.seg = 0;
   s.rough = 0;
+  s.o = s.d = s.energy = s.result = mk3(0.0f, 0.0f, 0.0f);
+  s.rng = Rng{0.0f, 0.0f, 0.0f};
   bool alive = false;
   uint32_t seg_total = 0, rough_total = 0, iters = 0;
   if ((x < fp.width) & (lrow < fp.local_rows)) {
@@ -383,11 +496,12 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   uint32_t live_waves = NW;
   __syncthreads();  // sphere records staged
   for (;;) {
-    if (alive) {
-      alive = path_step(sc, lds_sph, fp, s);
+    {
+      const bool was = alive;
+      alive = path_step_wave(sc, lds_sph, fp, s, alive);
       rough_total += s.rough;
       s.rough = 0;
-      if (!alive) {
+      if (was & !alive) {
         path_end(fp, s);
         seg_total += s.seg;
       }
@@ -478,6 +592,8 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
   s.p = 0;
   s.seg = 0;
   s.rough = 0;
+  s.o = s.d = s.energy = s.result = mk3(0.0f, 0.0f, 0.0f);
+  s.rng = Rng{0.0f, 0.0f, 0.0f};
   bool alive = false;
   uint32_t tile = 0, tpos = 64;  // wave-uniform cursor into the current tile
   bool work_left = n_tiles != 0u;
@@ -542,9 +658,10 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
       continue;
     }
     wave_iters += 1u;
-    if (alive) {
-      alive = path_step(sc, lds_sph, fp, s);
-      if (!alive) {
+    {
+      const bool was = alive;
+      alive = path_step_wave(sc, lds_sph, fp, s, alive);
+      if (was & !alive) {
         path_end(fp, s);
         seg_total += s.seg;
         rough_total += s.rough;
