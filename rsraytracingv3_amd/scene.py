@@ -253,6 +253,51 @@ class Scene:
             reflection_limit=reflection_limit)
 
     @staticmethod
+    def random_spheres_reference(min_radius: float = 3.0, max_radius: float = 8.0, placement_radius: float = 50.0,
+                                 sphere_count: int = 100, seed: int = 42) -> "Scene":
+        """scene.rs:152-231 on the reference's own random stream (``StdRng::seed_from_u64`` = ChaCha12,
+        ``rand_compat.StdRng``): reproduces the reference's default scene bit for bit — Sphere 0 matches
+        the values its screenshot shows.  float32 arithmetic follows the Rust expressions."""
+        from .rand_compat import StdRng
+        f = np.float32
+        rng = StdRng.seed_from_u64(seed)
+        objects: List[Object] = []
+        for i in range(sphere_count):
+            placed = None
+            for _ in range(100):                                   # scene.rs:104
+                radius = f(rng.gen_f32() * f(max_radius - min_radius) + f(min_radius))   # mul_add (scene.rs:105-107)
+                x, y = rng.unit_disc()                             # scene.rs:108
+                cx, cz = f(x * f(placement_radius)), f(y * f(placement_radius))
+                ok = True
+                for other in objects:                              # scene.rs:171-187
+                    oc = other.geometry.center
+                    dx, dy, dz = f(f(oc[0]) - cx), f(f(oc[1]) - radius), f(f(oc[2]) - cz)
+                    dist = f(np.sqrt(f(f(f(dx * dx) + f(dy * dy)) + f(dz * dz))))
+                    if dist < f(radius + f(other.geometry.radius)):
+                        ok = False
+                        break
+                if not ok:
+                    continue
+                colour = (float(rng.gen_f32()), float(rng.gen_f32()), float(rng.gen_f32()))
+                emission = _EMISSION_PALETTE[rng.gen_range_usize(0, 7)]
+                strength = float(rng.gen_range_f32_inclusive(5.0, 15.0)) if rng.gen_f32() > f(0.85) else 0.0
+                metallic = float(rng.gen_f32())
+                roughness = 0.0 if rng.gen_f32() < f(0.2) else float(rng.gen_f32())
+                placed = Object("Sphere %d" % i, Material(colour, emission, strength, metallic, roughness),
+                                Geometry.sphere((float(cx), float(radius), float(cz)), float(radius)))
+                break
+            if placed is not None:
+                objects.append(placed)
+        objects.append(Object("Plane", Material((0.5, 0.5, 0.5), (0., 0., 0.), 0., 0.2, 0.5),
+                              Geometry.plane((0., 0., 0.), (0., 1., 0.), 100_000.)))
+        return Scene(
+            objects=objects,
+            lights=[Light(0, (0.4, 0.4, 0.4), tuple(v / math.sqrt(3.5) for v in (-1., -1.5, -0.5))),
+                    Light(1, (0.4, 0.4, 0.4), (0., 2., 0.))],
+            camera=Camera((55., 65., 55.), (0.8, -0.8, 0.), 70.),
+            reflection_limit=3)
+
+    @staticmethod
     def random_spheres_default_config() -> "Scene":
-        """scene.rs:81-89 on a machine with more than two cores."""
-        return Scene.random_spheres(3., 8., 50., 100, 42)
+        """scene.rs:81-89 on a machine with more than two cores: the reference's start-up scene."""
+        return Scene.random_spheres_reference(3., 8., 50., 100, 42)
