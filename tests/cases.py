@@ -45,3 +45,12 @@ def horizon_scene(reflection_limit: int = 3) -> Scene:
 
 def inputs(sky_w=256, sky_h=128, rnd_seed=1):
     return synth.procedural_skybox(sky_w, sky_h), synth.random_texture(rnd_seed)
+
+
+def reference_default_scene(reflection_limit: int = 3) -> Scene:
+    """The reference's start-up scene (scene.rs:81-89, seed 42) regenerated on its own random stream,
+    seen from the camera of its screenshot."""
+    s = Scene.random_spheres_default_config()
+    s.reflection_limit = reflection_limit
+    s.camera = Camera((34.4, 37.3, 105.5), (0.5, -0.3, 0.0), 70.0)
+    return s

@@ -96,6 +96,17 @@ def test_live_count_equals_padded(device):
     assert_frame_equal(b[0], ref)
 
 
+def test_reference_default_scene_screenshot_view(device):
+    """The reference's own start-up scene (77 objects in its 80-slot buffer), its screenshot's camera
+    and bounce count, at the screenshot's panel aspect."""
+    scene = cases.reference_default_scene(3)
+    sky, rnd = cases.inputs(512, 256)
+    outs, st = run_gpu(device, scene, (294, 264), sky, rnd, (0.12, -0.34))
+    ref = run_oracle(scene, (294, 264), sky, rnd, (0.12, -0.34))
+    assert st.object_count == 80 and st.sphere_count == 79 and st.plane_count == 1
+    assert_frame_equal(outs[0], ref)
+
+
 def test_horizon_view(device):
     """Screenshot camera: sky rows exit after one segment, sphere rows bounce."""
     scene = cases.horizon_scene(3)
