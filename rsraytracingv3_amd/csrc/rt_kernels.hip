@@ -735,6 +735,8 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     variant = (tiles * sc.n_sph_pad >= 6000000ull) ? 2 : 3;
   }
   if (variant == 3 && fp.reflection_limit > 63u) variant = 0;  // the packed path state keeps 6 bits of bounce count
+  // scenes whose sphere records do not fit a workgroup's default 64 KB of LDS are scanned from global memory
+  if (lds + (variant == 3 ? 16384u : 0u) > 60u * 1024u) variant = 1;
   if (variant == 2) {
     uint32_t blocks = static_cast<uint32_t>(lc.persistent_blocks);
     const uint64_t max_useful = (tiles + (kBlock / 64) - 1) / (kBlock / 64);

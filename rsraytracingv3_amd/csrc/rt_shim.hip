@@ -637,11 +637,11 @@ int rt_sync(rt_context *ctx) {
   return RT_OK;
 }
 
-int rt_read_rgba8(rt_context *ctx, void *dst, size_t bytes) {
-  return read_back(ctx, ctx ? ctx->d_rgba8 : nullptr, dst, bytes, 4, "rt_read_rgba8");
+int rt_read_rgba8(rt_context *ctx, void *dst, size_t bytes) {  // caller-bound buffers take precedence
+  return read_back(ctx, ctx ? (ctx->ext_rgba8 ? ctx->ext_rgba8 : ctx->d_rgba8) : nullptr, dst, bytes, 4, "rt_read_rgba8");
 }
 int rt_read_rgbf32(rt_context *ctx, float *dst, size_t bytes) {
-  return read_back(ctx, ctx ? ctx->d_rgbf32 : nullptr, dst, bytes, 12, "rt_read_rgbf32");
+  return read_back(ctx, ctx ? (ctx->ext_rgba8 ? ctx->ext_rgbf32 : ctx->d_rgbf32) : nullptr, dst, bytes, 12, "rt_read_rgbf32");
 }
 int rt_read_segments(rt_context *ctx, uint32_t *dst, size_t bytes) {
   return read_back(ctx, ctx ? ctx->d_segments : nullptr, dst, bytes, 4, "rt_read_segments");
@@ -658,7 +658,8 @@ int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes) {
   const size_t need = static_cast<size_t>(ctx->local_rows) * ctx->width * 4;
   if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_write_history_rgba8: %zu bytes given, %zu expected", bytes, need);
   RT_HIP(ctx, hipSetDevice(ctx->device));
-  RT_HIP(ctx, hipMemcpyAsync(ctx->d_rgba8, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  uint32_t *history = ctx->ext_rgba8 ? (ctx->ext_hist_rgba8 ? ctx->ext_hist_rgba8 : ctx->ext_rgba8) : ctx->d_rgba8;
+  RT_HIP(ctx, hipMemcpyAsync(history, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }

@@ -208,3 +208,13 @@ def test_device_side_random_texture_matches_host_generator(device):
     device.sync()
     ref = reference(scene, (80, 45), sky, synth.random_texture(78), (0.3, 0.1))
     assert np.array_equal(target.read_rgbf32().view(np.uint32), ref.rgbf32.view(np.uint32))
+
+
+def test_scene_too_big_for_lds_falls_back_to_global_scan(device):
+    """4500 spheres = 72 KB of records: more than a workgroup's LDS, every shape must still agree."""
+    scene = cases.spheres_scene(4500, 4, seed=5, min_r=0.5, max_r=1.5, placement=260.0, request=4600)
+    sky, rnd = cases.inputs(64, 32)
+    ref = reference(scene, (40, 24), sky, rnd, slots="live")
+    for variant in (-1, 2, 3):
+        f, b, s = frame(device, scene, (40, 24), sky, rnd, slots="live", variant=variant)
+        assert np.array_equal(f.view(np.uint32), ref.rgbf32.view(np.uint32)), variant
