@@ -732,7 +732,9 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     // Measured on MI355X: block-compacting tiles win while a frame is a few waves
     // per SIMD deep; resident waves with lane refill win once there is enough work to amortise their
     // end-of-frame drain (4K frames, hundreds of spheres).
-    variant = (tiles * sc.n_sph_pad >= 6000000ull) ? 2 : 3;
+    // A frame too small to fill the chip more than once (a rank's share of a tile-split frame)
+    // gains nothing from re-packing and pays its barriers: plain tiles.
+    variant = (tiles * sc.n_sph_pad >= 6000000ull) ? 2 : (tiles < 24000ull ? 0 : 3);
   }
   if (variant == 3 && fp.reflection_limit > 63u) variant = 0;  // the packed path state keeps 6 bits of bounce count
   // scenes whose sphere records do not fit a workgroup's default 64 KB of LDS are scanned from global memory
