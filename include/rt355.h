@@ -68,6 +68,8 @@ typedef struct rt_stats {
   uint32_t _pad;
   uint64_t last_wave_iterations; /* variant 2: object scans executed by all waves (64 lanes each);
                                     last_segments / (64 * this) = lane occupancy of the scan */
+  uint64_t last_cull_mismatches; /* RT_OPT_CULL = 2: primary rays whose culled scan disagreed with the
+                                    full scan in the last frame (must be 0)                    */
 } rt_stats;
 
 /* Device-side view of the context's buffers, for zero-copy consumers (RCCL gather,
@@ -169,7 +171,9 @@ enum {
   RT_OPT_REFILL_MIN = 1,   /* variant 2: idle lanes a wave tolerates before pulling pixels (1..64) */
   RT_OPT_BLOCKS_PER_CU = 2,/* variant 2: resident workgroups per CU (0 = occupancy query)       */
   RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump */
-  RT_OPT_FLAGS = 4         /* experiment switches (speed only)                                     */
+  RT_OPT_FLAGS = 4,        /* experiment switches (speed only)                                     */
+  RT_OPT_CULL = 5          /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
+                              scan is re-done in full and disagreements are counted in rt_stats     */
 };
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RT355_LIB", os.path.join(_HERE, "librt355.so"))  # ov
 RT_OK = 0
 RT_ACCUM_SRGB8, RT_ACCUM_FLOAT32 = 0, 1
 RT_OUT_RGBA8, RT_OUT_RGBF32, RT_OUT_SEGMENTS, RT_OUT_HITS = 1, 2, 4, 8
-RT_OPT_VARIANT, RT_OPT_REFILL_MIN, RT_OPT_BLOCKS_PER_CU, RT_OPT_TILE_CHUNK = 0, 1, 2, 3
+RT_OPT_VARIANT, RT_OPT_REFILL_MIN, RT_OPT_BLOCKS_PER_CU, RT_OPT_TILE_CHUNK, RT_OPT_FLAGS, RT_OPT_CULL = 0, 1, 2, 3, 4, 5
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_NOT_READY",
                 -4: "RT_ERR_DEVICE", -5: "RT_ERR_OUT_OF_MEMORY"}
@@ -32,7 +32,7 @@ class RtStats(C.Structure):
                 ("last_pixels", C.c_uint64), ("last_kernel_ms", C.c_float), ("width", C.c_uint32),
                 ("height", C.c_uint32), ("local_rows", C.c_uint32), ("object_count", C.c_uint32),
                 ("sphere_count", C.c_uint32), ("plane_count", C.c_uint32), ("_pad", C.c_uint32),
-                ("last_wave_iterations", C.c_uint64)]
+                ("last_wave_iterations", C.c_uint64), ("last_cull_mismatches", C.c_uint64)]
 
 
 class RtDeviceBuffers(C.Structure):

@@ -65,6 +65,12 @@ struct FrameParams {
   unsigned int *tile_counters;   // variant 2: 8 work counters, 32 words (128 B) apart, zero at launch
   const float *srgb_lut;         // 256 decoded values
   int accum_mode;
+  // Primary-ray culling (variants 0, 1, 3): per 8x8 tile, a bit mask of the spheres whose inflated
+  // bound touches the tile's frustum (cull_tiles kernel); null = scan every sphere.  mask_words =
+  // 64-bit words per tile.  cull_check != 0: scan both ways and count disagreements in counters[3].
+  const unsigned long long *tile_masks;
+  uint32_t mask_words;
+  int cull_check;
 };
 
 // kernels (rt_kernels.hip)
@@ -80,6 +86,7 @@ int persistent_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);
 int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream);
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream);
+int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned long long *masks, hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);
 int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream);
 

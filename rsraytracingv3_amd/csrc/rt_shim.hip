@@ -77,6 +77,10 @@ struct rt_context {
   int cu_count = 0;
   int tile_chunk = 2;       // RT_OPT_TILE_CHUNK
   int flags = 0;            // RT_OPT_FLAGS
+  int cull = 1;             // RT_OPT_CULL: 0 off, 1 on, 2 on + self-check against the full scan
+  unsigned long long *d_masks = nullptr;  // per-tile sphere masks of the primary-ray culling
+  size_t masks_cap = 0;     // in 64-bit words
+  bool masks_dirty = true;  // scene, size or partition changed since the masks were built
   rt_stats stats{};
   std::string error;
 };
@@ -130,6 +134,7 @@ int alloc_target(rt_context *ctx) {
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   free_target(ctx);
   ctx->local_rows = count_local_rows(ctx->height, ctx->rank, ctx->world, ctx->strip_rows);
+  ctx->masks_dirty = true;
   const size_t px = static_cast<size_t>(ctx->local_rows) * ctx->width;
   if (px == 0) return RT_OK;
   RT_HIP(ctx, hipMalloc(&ctx->d_rgba8, px * 4));
@@ -248,6 +253,7 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_scene);
   (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_tile_counters);
+  (void)hipFree(ctx->d_masks);
   (void)hipFree(ctx->d_lut);
   for (int i = 0; i < 2; ++i)
     if (ctx->rnd_last_use[i]) (void)hipEventDestroy(ctx->rnd_last_use[i]);
@@ -455,6 +461,7 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   ctx->scene.n_pl = static_cast<uint32_t>(n_pl);
   ctx->scene.n_obj = object_count;
   ctx->have_scene = true;
+  ctx->masks_dirty = true;
   ctx->stats.object_count = object_count;
   ctx->stats.sphere_count = ctx->scene.n_sph;
   ctx->stats.plane_count = ctx->scene.n_pl;
@@ -511,6 +518,10 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       return RT_OK;
     case RT_OPT_FLAGS:
       ctx->flags = value;
+      return RT_OK;
+    case RT_OPT_CULL:
+      if (value < 0 || value > 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_CULL takes 0, 1 or 2");
+      ctx->cull = value;
       return RT_OK;
     case RT_OPT_TILE_CHUNK:
       ctx->tile_chunk = value < 1 ? 1 : value;
@@ -595,6 +606,32 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   fp.srgb_lut = ctx->d_lut;
   fp.accum_mode = ctx->accum_mode;
 
+  // Primary-ray culling masks: rebuilt when the scene, the size or the partition changed; valid for
+  // every jitter below half a pixel (larger jitters render without culling).
+  fp.tile_masks = nullptr;
+  fp.mask_words = 0;
+  fp.cull_check = 0;
+  if (ctx->cull != 0 && ctx->scene.n_sph != 0 && fabsf(jitter_x) <= 0.5f && fabsf(jitter_y) <= 0.5f) {
+    const uint32_t words = (ctx->scene.n_sph + 63u) / 64u;
+    const size_t tiles = static_cast<size_t>((ctx->width + 7) / 8) * ((ctx->local_rows + 7) / 8);
+    if (ctx->masks_cap < tiles * words) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->d_masks);
+      ctx->d_masks = nullptr;
+      ctx->masks_cap = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_masks, tiles * words * sizeof(unsigned long long)));
+      ctx->masks_cap = tiles * words;
+      ctx->masks_dirty = true;
+    }
+    fp.mask_words = words;
+    if (ctx->masks_dirty) {
+      if (launch_cull_tiles(ctx->scene, fp, ctx->d_masks, ctx->stream) != 0)
+        return fail(ctx, RT_ERR_DEVICE, "cull_tiles launch failed");
+      ctx->masks_dirty = false;
+    }
+    fp.tile_masks = ctx->d_masks;
+    fp.cull_check = ctx->cull == 2;
+  }
   if (slot % (rt_context::kRing / 2) == 0 && ctx->stats.frames != 0) {  // re-arm the half we are entering
     RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_counters + rt_context::kTileWords * static_cast<size_t>(slot), 0,
                                (rt_context::kRing / 2) * rt_context::kTileWords * sizeof(unsigned int), ctx->stream));
@@ -685,9 +722,10 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     std::vector<unsigned long long> line(rt_context::kCounterWords);
     RT_HIP(ctx, hipMemcpy(line.data(), ctx->d_counters + rt_context::kCounterWords * static_cast<size_t>(slot),
                           line.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    unsigned long long c[3] = {0, 0, 0};
+    unsigned long long c[4] = {0, 0, 0, 0};
     for (uint32_t sh = 0; sh < kTotalShards; ++sh)
-      for (int w = 0; w < 3; ++w) c[w] += line[sh * kTotalShardStride + w];
+      for (int w = 0; w < 4; ++w) c[w] += line[sh * kTotalShardStride + w];
+    ctx->stats.last_cull_mismatches = c[3];
     ctx->stats.last_segments = c[0];
     ctx->stats.last_rough_hits = c[1];
     ctx->stats.last_wave_iterations = c[2];

@@ -243,6 +243,36 @@ def test_tile_parallel_renderer_single_rank(device):
         device._keepalive_stream = private
 
 
+@pytest.mark.parametrize("variant", [0, 1, 3])
+def test_primary_ray_culling_never_disagrees_with_the_full_scan(device, variant):
+    """RT_OPT_CULL = 2 re-does every culled primary scan in full inside the kernel and counts
+    disagreements; cameras inside the sphere field, far away, looking up, wide and narrow fov."""
+    from rsraytracingv3_amd.scene import Camera
+    sky, rnd = cases.inputs(128, 64)
+    views = [((55., 65., 55.), (0.8, -0.8, 0.), 70.), ((34.4, 37.3, 105.5), (0.5, -0.3, 0.), 70.),
+             ((3., 2., 4.), (0.05, 2.2, 0.), 90.), ((0., 400., 0.), (1.55, 0., 0.), 20.),
+             ((10., 6., -30.), (-0.3, 3.0, 0.), 5.), ((0., 5., 0.), (-1.2, 0.7, 0.), 89.)]
+    for scene in (cases.headline_scene(3), cases.stress_scene(300, 2)):
+        for pos, rot, fov in views:
+            scene.camera = Camera(pos, rot, fov)
+            for jitter in ((0.0, 0.0), (0.495, -0.495), (-0.495, 0.495)):
+                device.set_option(N.RT_OPT_CULL, 2)
+                outs, st = run_gpu(device, scene, (203, 117), sky, rnd, jitter, max_objects="live", variant=variant)
+                assert st.last_cull_mismatches == 0, (pos, rot, fov, jitter)
+                device.set_option(N.RT_OPT_CULL, 0)
+                plain, _ = run_gpu(device, scene, (203, 117), sky, rnd, jitter, max_objects="live", variant=variant)
+                assert np.array_equal(outs[0][0].view(np.uint32), plain[0][0].view(np.uint32))
+    device.set_option(N.RT_OPT_CULL, 1)
+
+
+def test_jitter_beyond_half_a_pixel_renders_without_culling(device):
+    scene = cases.headline_scene(3)
+    sky, rnd = cases.inputs(128, 64)
+    outs, _ = run_gpu(device, scene, (120, 64), sky, rnd, (3.25, -2.5))
+    ref = run_oracle(scene, (120, 64), sky, rnd, (3.25, -2.5))
+    assert_frame_equal(outs[0], ref)
+
+
 def test_device_math_bitwise(device):
     """The device build of every specified math function equals the oracle's, bit for bit."""
     import ctypes as C
