@@ -830,12 +830,12 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   const size_t lds = static_cast<size_t>(sc.n_sph_pad) * sizeof(float4);
   int variant = lc.variant;
   if (variant < 0) {
-    // Measured on MI355X: block-compacting tiles win while a frame is a few waves
-    // per SIMD deep; resident waves with lane refill win once there is enough work to amortise their
-    // end-of-frame drain (4K frames, hundreds of spheres).
-    // A frame too small to fill the chip more than once (a rank's share of a tile-split frame)
-    // gains nothing from re-packing and pays its barriers: plain tiles.
-    variant = (tiles * sc.n_sph_pad >= 6000000ull) ? 2 : (tiles < 24000ull ? 0 : 3);
+    // Measured on MI355X.  Re-packing a workgroup's surviving paths pays once a frame
+    // fills the chip more than once and the scan is short enough for the per-bounce barrier to matter
+    // little; scenes with hundreds of spheres and small frames (a rank's share of a tile-split frame)
+    // are fastest as plain tiles.  The resident-wave shape (2) is never the fastest since the
+    // primary-ray culling, which it cannot use; it stays selectable.
+    variant = (sc.n_sph_pad > 128u || tiles < 24000ull) ? 0 : 3;
   }
   if (variant == 3 && fp.reflection_limit > 63u) variant = 0;  // the packed path state keeps 6 bits of bounce count
   // scenes whose sphere records do not fit a workgroup's default 64 KB of LDS are scanned from global memory
