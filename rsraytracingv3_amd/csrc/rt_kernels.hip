@@ -540,6 +540,10 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   __syncthreads();  // sphere records staged
   const unsigned long long *primary_mask =
       fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tile) * fp.mask_words : nullptr;
+  // A finished path keeps its result in the lane's registers and is written out (sRGB encode +
+  // stores, ~150 instructions) together with the other finished lanes when the lane is about to be
+  // re-used or the wave ends, not one partial-wave call per bounce.
+  bool finished = false;
   for (;;) {
     {
       const bool was = alive;
@@ -547,10 +551,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
       primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
       rough_total += s.rough;
       s.rough = 0;
-      if (was & !alive) {
-        path_end(fp, s);
-        seg_total += s.seg;
-      }
+      finished |= was & !alive;
     }
     iters += 1u;
     const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
@@ -576,6 +577,11 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
         q[2] = make_float4(s.energy.z, s.result.x, s.result.y, s.result.z);
         q[3] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p | (s.seg << 26)));
       }
+      if (finished) {  // the lane's registers are about to change hands
+        path_end(fp, s);
+        seg_total += s.seg;
+        finished = false;
+      }
       __syncthreads();
       if (wave >= need) break;  // surplus wave: its paths now live in a lower wave
       const uint32_t r = wave * 64u + lane;
@@ -597,6 +603,10 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
       // No barrier here: the exchange buffer is next written after the next count barrier, which the
       // surviving waves only pass once their reads above have completed.
     }
+  }
+  if (finished) {
+    path_end(fp, s);
+    seg_total += s.seg;
   }
   // totals: one atomic set per wave on the workgroup's shard (waves end at different times here)
 #pragma unroll
