@@ -337,12 +337,19 @@ __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, ui
 
 // shade() of one iteration of frag.hlsl:36-43 for the hit `h`; x1 is the first random() texel value,
 // requested before the scan.  Returns whether the loop goes on.
+// DEFER_SKY: on a miss only mark the path; its skybox texel is fetched in path_end (pays where
+// path_end runs once per wave with all finished lanes, i.e. the plain tile kernel).
+template <bool DEFER_SKY>
 __device__ __forceinline__ bool path_shade(const DeviceScene &sc, const float4 *__restrict__ sph,
                                            const FrameParams &fp, Path &s, const Hit h, const float x1) {
   if (fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
   s.seg += 1;
   if (h.obj < 0) {  // frag.hlsl:14-17: miss -> skybox, energy 0, loop ends (|0| < EPSILON)
-    s.result = fma3(s.energy, sample_hdri(fp, s.d), s.result);
+    if (DEFER_SKY) {
+      s.rough |= 0x80000000u;  // "ended on a miss": path_end<true> adds energy * skybox(d)
+    } else {
+      s.result = fma3(s.energy, sample_hdri(fp, s.d), s.result);
+    }
     return false;
   }
   const f3 pos = fma3(s.d, h.t, s.o);
@@ -371,17 +378,19 @@ __device__ __forceinline__ bool path_shade(const DeviceScene &sc, const float4 *
 }
 
 // One iteration of frag.hlsl:36-43 (ray_intersect + shade) for the calling lanes (one ray each).
+template <bool DEFER_SKY>
 __device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *__restrict__ sph,
                                           const FrameParams &fp, Path &s) {
   // Requested now, used after the scan if the hit is rough: the gather's latency (an L2 round trip)
   // hides under the object scan instead of heading the shading chain.
   const float x1 = fp.rnd[rng_texel(fp, s.rng)];
   const Hit h = finish_hit(sc, scan_spheres(sc, sph, s.o, s.d), s.o, s.d);
-  return path_shade(sc, sph, fp, s, h, x1);
+  return path_shade<DEFER_SKY>(sc, sph, fp, s, h, x1);
 }
 
 // The same for a whole wave (every lane calls it; `alive` = this lane carries a ray): picks the
 // wave-cooperative scan when at most 16 lanes are live.  Returns the lane's new `alive`.
+template <bool DEFER_SKY>
 __device__ __forceinline__ bool path_step_wave(const DeviceScene &sc, const float4 *__restrict__ sph,
                                                const FrameParams &fp, Path &s, bool alive,
                                                const unsigned long long *__restrict__ primary_mask = nullptr) {
@@ -396,23 +405,26 @@ __device__ __forceinline__ bool path_step_wave(const DeviceScene &sc, const floa
         const SphereHit full = scan_spheres(sc, sph, s.o, s.d);
         if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
       }
-      alive = path_shade(sc, sph, fp, s, finish_hit(sc, sh, s.o, s.d), x1);
+      alive = path_shade<DEFER_SKY>(sc, sph, fp, s, finish_hit(sc, sh, s.o, s.d), x1);
     }
   } else if (n_live <= 16u) {
     float x1 = 0.0f;
     if (alive) x1 = fp.rnd[rng_texel(fp, s.rng)];
     const SphereHit sh = scan_spheres_coop(sc, sph, s.o, s.d, alive, live, n_live);
-    if (alive) alive = path_shade(sc, sph, fp, s, finish_hit(sc, sh, s.o, s.d), x1);
+    if (alive) alive = path_shade<DEFER_SKY>(sc, sph, fp, s, finish_hit(sc, sh, s.o, s.d), x1);
   } else if (alive) {
-    alive = path_step(sc, sph, fp, s);
+    alive = path_step<DEFER_SKY>(sc, sph, fp, s);
   }
   return alive;
 }
 
 // frag.hlsl:60-65 + the Rgba8UnormSrgb store (D13).  At progressive_count 0 the history weight
 // is exactly 0, so the history is not read.
+template <bool DEFER_SKY = false>
 __device__ __forceinline__ void path_end(const FrameParams &fp, const Path &s) {
   const size_t p = s.p;
+  f3 result = s.result;
+  if (DEFER_SKY && (s.rough & 0x80000000u)) result = fma3(s.energy, sample_hdri(fp, s.d), result);  // frag.hlsl:14-17, D1
   f3 prev = mk3(0.0f, 0.0f, 0.0f);
   if (fp.progressive_count != 0u) {
     if (fp.accum_mode == 1) {
@@ -422,7 +434,7 @@ __device__ __forceinline__ void path_end(const FrameParams &fp, const Path &s) {
       prev = mk3(fp.srgb_lut[w & 255u], fp.srgb_lut[(w >> 8) & 255u], fp.srgb_lut[(w >> 16) & 255u]);
     }
   }
-  const f3 mixed = fma3(s.result, fp.opacity, prev * fp.keep);
+  const f3 mixed = fma3(result, fp.opacity, prev * fp.keep);
   fp.rgba8[p] = srgb8_encode_spec(mixed.x) | (srgb8_encode_spec(mixed.y) << 8) |
                 (srgb8_encode_spec(mixed.z) << 16) | 0xff000000u;
   if (fp.rgbf32) {
@@ -492,12 +504,12 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
     alive = fp.reflection_limit != 0u;
   }
   if (fp.tile_masks != nullptr && __builtin_amdgcn_ballot_w64(alive) != 0ull)
-    alive = path_step_wave(sc, sph, fp, s, alive, fp.tile_masks + static_cast<size_t>(wave) * fp.mask_words);
-  while (__builtin_amdgcn_ballot_w64(alive) != 0ull) alive = path_step_wave(sc, sph, fp, s, alive);
+    alive = path_step_wave<true>(sc, sph, fp, s, alive, fp.tile_masks + static_cast<size_t>(wave) * fp.mask_words);
+  while (__builtin_amdgcn_ballot_w64(alive) != 0ull) alive = path_step_wave<true>(sc, sph, fp, s, alive);
   if (valid) {
-    path_end(fp, s);
+    path_end<true>(fp, s);
     seg = s.seg;
-    rough = s.rough;
+    rough = s.rough & 0x7fffffffu;
   }
   add_totals(fp, seg, rough, 0u);
 }
@@ -547,7 +559,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   for (;;) {
     {
       const bool was = alive;
-      alive = path_step_wave(sc, lds_sph, fp, s, alive, primary_mask);
+      alive = path_step_wave<false>(sc, lds_sph, fp, s, alive, primary_mask);
       primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
       rough_total += s.rough;
       s.rough = 0;
@@ -716,7 +728,7 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
     wave_iters += 1u;
     {
       const bool was = alive;
-      alive = path_step_wave(sc, lds_sph, fp, s, alive);
+      alive = path_step_wave<false>(sc, lds_sph, fp, s, alive);
       if (was & !alive) {
         path_end(fp, s);
         seg_total += s.seg;
