@@ -65,9 +65,10 @@ struct FrameParams {
   unsigned int *tile_counters;   // variant 2: 8 work counters, 32 words (128 B) apart, zero at launch
   const float *srgb_lut;         // 256 decoded values
   int accum_mode;
-  // Primary-ray culling (variants 0, 1, 3): per 8x8 tile, a bit mask of the spheres whose inflated
-  // bound touches the tile's frustum (cull_tiles kernel); null = scan every sphere.  mask_words =
-  // 64-bit words per tile.  cull_check != 0: scan both ways and count disagreements in counters[3].
+  // Primary-ray culling (variants 0, 1, 3): bit masks of the spheres whose inflated bound touches a
+  // tile column's / tile row's slab of rays (cull_slabs kernel): [tiles_x column masks][tiles_y row
+  // masks], mask_words 64-bit words each; a tile scans column & row.  null = scan every sphere.
+  // cull_check != 0: scan both ways and count disagreements in counters[3].
   const unsigned long long *tile_masks;
   uint32_t mask_words;
   int cull_check;

@@ -249,12 +249,14 @@ __device__ __forceinline__ SphereHit scan_spheres_coop(const DeviceScene &sc, co
 // Used for the primary rays of a tile, whose mask comes from cull_tiles: a sphere outside the mask
 // cannot be accepted by any ray of the tile, so skipping it does not change the result.
 __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restrict__ sph, f3 o, f3 d,
-                                                         const unsigned long long *__restrict__ mask, uint32_t words) {
+                                                         const unsigned long long *__restrict__ col_mask,
+                                                         const unsigned long long *__restrict__ row_mask, uint32_t words) {
   uint32_t best_key = kNoHitKey;
   int slot = -1;
   for (uint32_t w = 0; w < words; ++w) {
-    // the mask address is the same in every lane: read once, keep in SGPRs
-    unsigned long long m = mask[w];
+    // a tile's spheres = those inside its column slab AND its row slab; the addresses are the same
+    // in every lane: read once, keep in SGPRs
+    unsigned long long m = col_mask[w] & row_mask[w];
     m = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(m >> 32))) << 32) |
         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(m)));
     while (m != 0ull) {
@@ -393,14 +395,15 @@ __device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *_
 template <bool DEFER_SKY>
 __device__ __forceinline__ bool path_step_wave(const DeviceScene &sc, const float4 *__restrict__ sph,
                                                const FrameParams &fp, Path &s, bool alive,
-                                               const unsigned long long *__restrict__ primary_mask = nullptr) {
+                                               const unsigned long long *__restrict__ primary_mask = nullptr,
+                                               const unsigned long long *__restrict__ primary_mask2 = nullptr) {
   const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
   const uint32_t n_live = static_cast<uint32_t>(__popcll(live));
   if (n_live == 0u) return false;
   if (primary_mask != nullptr) {  // wave-uniform: all live lanes carry primary rays of one tile
     if (alive) {
       const float x1 = fp.rnd[rng_texel(fp, s.rng)];
-      const SphereHit sh = scan_spheres_listed(sph, s.o, s.d, primary_mask, fp.mask_words);
+      const SphereHit sh = scan_spheres_listed(sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
       if (fp.cull_check) {  // self-check build of the frame: the full scan must agree
         const SphereHit full = scan_spheres(sc, sph, s.o, s.d);
         if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
@@ -504,7 +507,8 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
     alive = fp.reflection_limit != 0u;
   }
   if (fp.tile_masks != nullptr && __builtin_amdgcn_ballot_w64(alive) != 0ull)
-    alive = path_step_wave<true>(sc, sph, fp, s, alive, fp.tile_masks + static_cast<size_t>(wave) * fp.mask_words);
+    alive = path_step_wave<true>(sc, sph, fp, s, alive, fp.tile_masks + static_cast<size_t>(wave % tiles_x) * fp.mask_words,
+                                 fp.tile_masks + static_cast<size_t>(tiles_x + wave / tiles_x) * fp.mask_words);
   while (__builtin_amdgcn_ballot_w64(alive) != 0ull) alive = path_step_wave<true>(sc, sph, fp, s, alive);
   if (valid) {
     path_end<true>(fp, s);
@@ -551,7 +555,9 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   uint32_t live_waves = NW;
   __syncthreads();  // sphere records staged
   const unsigned long long *primary_mask =
-      fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tile) * fp.mask_words : nullptr;
+      fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tile % tiles_x) * fp.mask_words : nullptr;
+  const unsigned long long *primary_mask2 =
+      fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tiles_x + tile / tiles_x) * fp.mask_words : nullptr;
   // A finished path keeps its result in the lane's registers and is written out (sRGB encode +
   // stores, ~150 instructions) together with the other finished lanes when the lane is about to be
   // re-used or the wave ends, not one partial-wave call per bounce.
@@ -559,7 +565,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   for (;;) {
     {
       const bool was = alive;
-      alive = path_step_wave<false>(sc, lds_sph, fp, s, alive, primary_mask);
+      alive = path_step_wave<false>(sc, lds_sph, fp, s, alive, primary_mask, primary_mask2);
       primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
       rough_total += s.rough;
       s.rough = 0;
@@ -739,43 +745,53 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
   add_totals(fp, seg_total, rough_total, wave_iters);
 }
 
-// Primary-ray culling pre-pass: one wave per 8x8 tile, lane k tests sphere 64*w + k against the
-// tile's frustum — the four planes through the camera and the tile's corner rays, the tile grown by
-// one pixel on every side (the jitter is below half a pixel, connection.rs:20).  A sphere is dropped
-// only if it lies entirely outside one side plane even after its radius is inflated by
-// 0.1 % + 0.2 % of its distance to the camera: that margin exceeds the rounding error with which the
-// float test of ray.hlsl:53-68 can still report a hit for a ray that geometrically misses
-// (|q_float - q| <= 16 * 2^-24 * (D^2 + r^2), i.e. an effective radius error below 0.1 % of D).
-// The mask of a tile = ballot of the surviving lanes.
-__global__ void __launch_bounds__(256) cull_tiles_kernel(DeviceScene sc, FrameParams fp, unsigned long long *masks,
-                                                         uint32_t n_tiles) {
+// Primary-ray culling pre-pass.  The rays of one pixel column lie in a plane through the camera
+// (pixel_world_space is affine in v, ray.hlsl:31-35), and so do the rays of one pixel row, so a tile's
+// frustum is the intersection of a column slab (between two such planes) and a row slab, and the set
+// of spheres that can touch it factorises: mask(tile) = column_mask[tx] & row_mask[ty].  One wave per
+// slab, lane k tests sphere 64*w + k; slabs are grown by one pixel on either side (the jitter is below
+// half a pixel, connection.rs:20) and a sphere is dropped only if it lies entirely outside a slab even
+// after its radius is inflated by 0.1 % + 0.2 % of its distance to the camera.  That margin exceeds
+// the rounding error with which the float test of ray.hlsl:53-68 can still report a hit for a ray
+// that geometrically misses (|q_float - q| <= 16 * 2^-24 * (D^2 + r^2): an effective radius error
+// below 0.1 % of the distance D).  masks = [tiles_x column masks][tiles_y row masks], `mask_words`
+// 64-bit words each.
+__global__ void __launch_bounds__(256) cull_slabs_kernel(DeviceScene sc, FrameParams fp, unsigned long long *masks,
+                                                         uint32_t tiles_x, uint32_t tiles_y) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (tile >= n_tiles) return;
-  const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-  const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-  // pixel rectangle of the tile in full-frame coordinates; rows follow the strip partition
-  const uint32_t lr0 = ty * kTile, lr1 = min(lr0 + kTile - 1u, fp.local_rows - 1u);
-  const uint32_t y0 = ((lr0 / fp.strip_rows) * fp.world + fp.rank) * fp.strip_rows + lr0 % fp.strip_rows;
-  const uint32_t y1 = ((lr1 / fp.strip_rows) * fp.world + fp.rank) * fp.strip_rows + lr1 % fp.strip_rows;
-  const float px0 = static_cast<float>(tx * kTile) - 1.0f, px1 = static_cast<float>(min(tx * kTile + kTile, fp.width)) + 1.0f;
-  const float py0 = static_cast<float>(y0) - 1.0f, py1 = static_cast<float>(y1 + 1u) + 1.0f;
-  const float u0 = px0 / static_cast<float>(fp.width), u1 = px1 / static_cast<float>(fp.width);
-  const float v0 = py0 / static_cast<float>(fp.height), v1 = py1 / static_cast<float>(fp.height);
-  // corner ray directions (not normalised), same construction as create_ray (ray.hlsl:31-37)
-  auto corner = [&](float u, float v) {
+  const uint32_t slab = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (slab >= tiles_x + tiles_y) return;
+  auto corner = [&](float u, float v) {  // ray direction (not normalised) of normalised pixel (u, v)
     f3 p = fma3(fp.cam_right, u * fp.vp_width, fp.top_left);
     p = fma3(fp.cam_neg_up, v * fp.vp_height, p);
     return p - fp.cam_pos;
   };
-  const f3 d00 = corner(u0, v0), d10 = corner(u1, v0), d01 = corner(u0, v1), d11 = corner(u1, v1);
-  const f3 axis = (d00 + d11) + (d10 + d01);
-  // inward unit normals of the four side planes, oriented with the frustum axis
-  auto side = [&](f3 a, f3 b) {
-    f3 n = normalize3(cross3(a, b));
-    return dot3(n, axis) < 0.0f ? -n : n;
-  };
-  const f3 n_top = side(d00, d10), n_bottom = side(d01, d11), n_left = side(d00, d01), n_right = side(d10, d11);
+  f3 n_lo, n_hi;  // inward unit normals of the slab's two bounding planes
+  if (slab < tiles_x) {
+    const float px0 = static_cast<float>(slab * kTile) - 1.0f;
+    const float px1 = static_cast<float>(min(slab * kTile + kTile, fp.width)) + 1.0f;
+    const float u0 = px0 / static_cast<float>(fp.width), u1 = px1 / static_cast<float>(fp.width);
+    const f3 a0 = corner(u0, 0.0f), b0 = corner(u0, 1.0f), a1 = corner(u1, 0.0f), b1 = corner(u1, 1.0f);
+    const f3 inside = (a0 + b0) + (a1 + b1);
+    n_lo = normalize3(cross3(a0, b0));
+    n_hi = normalize3(cross3(a1, b1));
+    if (dot3(n_lo, inside) < 0.0f) n_lo = -n_lo;
+    if (dot3(n_hi, inside) < 0.0f) n_hi = -n_hi;
+  } else {
+    const uint32_t ty = slab - tiles_x;
+    // rows of this tile row in full-frame coordinates (local rows follow the strip partition)
+    const uint32_t lr0 = ty * kTile, lr1 = min(lr0 + kTile - 1u, fp.local_rows - 1u);
+    const uint32_t y0 = ((lr0 / fp.strip_rows) * fp.world + fp.rank) * fp.strip_rows + lr0 % fp.strip_rows;
+    const uint32_t y1 = ((lr1 / fp.strip_rows) * fp.world + fp.rank) * fp.strip_rows + lr1 % fp.strip_rows;
+    const float v0 = (static_cast<float>(y0) - 1.0f) / static_cast<float>(fp.height);
+    const float v1 = (static_cast<float>(y1 + 1u) + 1.0f) / static_cast<float>(fp.height);
+    const f3 a0 = corner(0.0f, v0), b0 = corner(1.0f, v0), a1 = corner(0.0f, v1), b1 = corner(1.0f, v1);
+    const f3 inside = (a0 + b0) + (a1 + b1);
+    n_lo = normalize3(cross3(a0, b0));
+    n_hi = normalize3(cross3(a1, b1));
+    if (dot3(n_lo, inside) < 0.0f) n_lo = -n_lo;
+    if (dot3(n_hi, inside) < 0.0f) n_hi = -n_hi;
+  }
   const uint32_t words = fp.mask_words;
   for (uint32_t w = 0; w < words; ++w) {
     const uint32_t i = w * 64u + lane;
@@ -785,12 +801,12 @@ __global__ void __launch_bounds__(256) cull_tiles_kernel(DeviceScene sc, FramePa
       const f3 rel = mk3(g.x, g.y, g.z) - fp.cam_pos;
       const float dist = length3(rel);
       const float r = sqrtf(fmaxf(g.w, 0.0f)) * 1.001f + 0.002f * dist + 1e-6f;
-      keep = (dot3(n_top, rel) >= -r) & (dot3(n_bottom, rel) >= -r) & (dot3(n_left, rel) >= -r) &
-             (dot3(n_right, rel) >= -r);
-      keep |= !(dist == dist);  // NaN anywhere: keep
+      const float dlo = dot3(n_lo, rel), dhi = dot3(n_hi, rel);
+      keep = (dlo >= -r) & (dhi >= -r);
+      keep |= !(dlo == dlo) | !(dhi == dhi) | !(r == r);  // NaN anywhere: keep
     }
     const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-    if (lane == 0) masks[static_cast<size_t>(tile) * words + w] = m;
+    if (lane == 0) masks[static_cast<size_t>(slab) * words + w] = m;
   }
 }
 
@@ -888,9 +904,9 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
 int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned long long *masks, hipStream_t stream) {
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
   const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
-  const uint32_t n_tiles = tiles_x * tiles_y;
-  if (n_tiles == 0 || fp.mask_words == 0) return 0;
-  hipLaunchKernelGGL(cull_tiles_kernel, dim3((n_tiles + 3) / 4), dim3(256), 0, stream, sc, fp, masks, n_tiles);
+  if (tiles_x * tiles_y == 0 || fp.mask_words == 0) return 0;
+  hipLaunchKernelGGL(cull_slabs_kernel, dim3((tiles_x + tiles_y + 3) / 4), dim3(256), 0, stream, sc, fp, masks, tiles_x,
+                     tiles_y);
   return static_cast<int>(hipGetLastError());
 }
 

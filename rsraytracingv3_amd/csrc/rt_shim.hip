@@ -613,7 +613,7 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   fp.cull_check = 0;
   if (ctx->cull != 0 && ctx->scene.n_sph != 0 && fabsf(jitter_x) <= 0.5f && fabsf(jitter_y) <= 0.5f) {
     const uint32_t words = (ctx->scene.n_sph + 63u) / 64u;
-    const size_t tiles = static_cast<size_t>((ctx->width + 7) / 8) * ((ctx->local_rows + 7) / 8);
+    const size_t tiles = static_cast<size_t>((ctx->width + 7) / 8) + ((ctx->local_rows + 7) / 8);  // column + row slabs
     if (ctx->masks_cap < tiles * words) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
       (void)hipFree(ctx->d_masks);
