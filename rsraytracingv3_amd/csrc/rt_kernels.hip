@@ -35,6 +35,10 @@ namespace {
 #endif
 constexpr int kBlock = 256;
 constexpr int kTile = 8;  // 8x8 pixels per tile / wave
+#ifndef RT_XCHG_PATHS
+#define RT_XCHG_PATHS 192  // re-packing needs the paths to fit 3 waves or fewer
+#endif
+constexpr uint32_t kXchgPaths = RT_XCHG_PATHS;  // paths the block kernel's LDS exchange buffer holds
 
 // Correctly rounded sqrt for x >= 2^-96 (also +0, +inf, NaN): v_sqrt_f32 is within 1 ulp, so
 // the IEEE result is one of {s-1ulp, s, s+1ulp}; the signs of the two fused residuals pick it
@@ -531,7 +535,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   extern __shared__ float4 lds_all[];
   __shared__ unsigned int wave_count[NW];
   float4 *lds_sph = lds_all;
-  float4 *xchg = lds_all + sc.n_sph_pad;  // NW*64 paths x 4 float4
+  float4 *xchg = lds_all + sc.n_sph_pad;  // kXchgPaths paths x 4 float4
   for (uint32_t i = threadIdx.x; i < sc.n_sph_pad; i += NW * 64) lds_sph[i] = sc.sph[i];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -584,7 +588,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
     }
     if (total == 0u) break;
     const uint32_t need = (total + 63u) >> 6;
-    if (need < live_waves) {
+    if (need < live_waves && total <= kXchgPaths) {
       // pack: path number = paths in lower waves + live lanes below this one
       if (alive) {
         const uint32_t r = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
@@ -877,7 +881,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   }
   if (variant == 3 && fp.reflection_limit > 63u) variant = 0;  // the packed path state keeps 6 bits of bounce count
   // scenes whose sphere records do not fit a workgroup's default 64 KB of LDS are scanned from global memory
-  if (lds + (variant == 3 ? 16384u : 0u) > 60u * 1024u) variant = 1;
+  if (lds + (variant == 3 ? kXchgPaths * 64u : 0u) > 60u * 1024u) variant = 1;
   if (variant == 2) {
     uint32_t blocks = static_cast<uint32_t>(lc.persistent_blocks);
     const uint64_t max_useful = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
@@ -888,7 +892,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
                        static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 3) {
     const uint32_t blocks = static_cast<uint32_t>((tiles + 3) / 4);
-    const size_t bytes = lds + static_cast<size_t>(4) * 64 * 4 * sizeof(float4);
+    const size_t bytes = lds + static_cast<size_t>(kXchgPaths) * 4 * sizeof(float4);
     hipLaunchKernelGGL(render_blocks<4>, dim3(blocks), dim3(256), bytes, stream, sc, fp);
   } else {
     const uint32_t blocks = static_cast<uint32_t>((tiles + (kBlock / 64) - 1) / (kBlock / 64));
