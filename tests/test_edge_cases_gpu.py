@@ -218,3 +218,49 @@ def test_scene_too_big_for_lds_falls_back_to_global_scan(device):
     for variant in (-1, 2, 3):
         f, b, s = frame(device, scene, (40, 24), sky, rnd, slots="live", variant=variant)
         assert np.array_equal(f.view(np.uint32), ref.rgbf32.view(np.uint32)), variant
+
+
+def test_two_contexts_on_one_gpu_do_not_interfere(device):
+    """Two rt_contexts (own streams, own buffers) rendering different scenes back to back."""
+    other = Device(0)
+    try:
+        sky, rnd = cases.inputs(64, 32)
+        a_scene, b_scene = cases.headline_scene(5), cases.config1_scene()
+        b_scene.reflection_limit = 4
+        setups = []
+        for dev, scene, size in ((device, a_scene, (96, 56)), (other, b_scene, (72, 40))):
+            dev.set_partition(0, 1, 8)
+            dev.set_accum_mode(N.RT_ACCUM_SRGB8)
+            dev.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
+            dev.set_variant(-1)
+            target = RenderTarget.new(dev, size)
+            rt = RandomTexture(dev)
+            rt.write(rnd)
+            conn = Connection(scene, dev, sky, rt)
+            setups.append((dev, scene, size, target, conn))
+        for _ in range(3):            # interleave launches of both contexts without syncing in between
+            for dev, scene, size, target, conn in setups:
+                conn.update_buffers(size, scene, (0.2, 0.2))
+                conn.frame_data.progressive_count = 0
+                conn.draw()
+        for dev, scene, size, target, conn in setups:
+            dev.sync()
+            ref = reference(scene, size, sky, rnd, (0.2, 0.2))
+            assert np.array_equal(target.read_rgbf32().view(np.uint32), ref.rgbf32.view(np.uint32))
+    finally:
+        other.close()
+
+
+def test_destroy_with_frames_in_flight():
+    dev = Device(0)
+    scene = cases.headline_scene(8)
+    sky, rnd = cases.inputs(64, 32)
+    dev.set_outputs(N.RT_OUT_RGBA8)
+    RenderTarget.new(dev, (640, 360))
+    rt = RandomTexture(dev)
+    rt.write(rnd)
+    conn = Connection(scene, dev, sky, rt)
+    conn.update_buffers((640, 360), scene, (0.0, 0.0))
+    for _ in range(20):
+        conn.draw()
+    dev.close()     # rt_destroy waits for the stream before freeing anything
