@@ -26,8 +26,10 @@ class FrameGatherer:
     """Gathers per-rank compact strip buffers (padded to the largest piece) on rank 0 and
     de-interleaves them into the (height, width[, C]) frame with one index_select."""
 
-    def __init__(self, height: int, width: int, strip_rows: int, device: torch.device, group=None):
+    def __init__(self, height: int, width: int, strip_rows: int, device: torch.device, group=None,
+                 force_collective: bool = False):
         self.group = group
+        self.force_collective = force_collective  # world 1 still goes through dist.gather (RCCL smoke test)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.height, self.width, self.strip_rows = height, width, strip_rows
@@ -52,8 +54,8 @@ class FrameGatherer:
 
     def gather(self, local: torch.Tensor, async_op: bool = False):
         """Collective.  Returns (stacked buffer on rank 0 | None, work handle | None)."""
-        if self.world == 1:
-            return local, None
+        if self.world == 1 and not (self.force_collective and dist.is_initialized()):
+            return local.unsqueeze(0), None
         if self.via_host:
             torch.cuda.current_stream(self.device).synchronize()
             host = local.cpu()
@@ -73,8 +75,7 @@ class FrameGatherer:
 
     def assemble(self, stacked: torch.Tensor) -> torch.Tensor:
         """Rank 0: stacked (world, padded_rows, W[, C]) -> frame (height, W[, C])."""
-        flat = stacked.reshape((-1,) + tuple(stacked.shape[2:])) if stacked.dim() >= 3 and self.world > 1 \
-            else stacked
+        flat = stacked.reshape((-1,) + tuple(stacked.shape[2:]))
         return flat.index_select(0, self.row_source)
 
 
@@ -88,10 +89,11 @@ class TileParallelRenderer:
       3. start gather(k) asynchronously — RCCL orders it after render(k) on the current stream.
     ``finish`` drains the pipeline and returns the last frame."""
 
-    def __init__(self, rt_device, width: int, height: int, strip_rows: int = 8, group=None):
+    def __init__(self, rt_device, width: int, height: int, strip_rows: int = 8, group=None,
+                 force_collective: bool = False):
         self.rt = rt_device
         self.torch_device = torch.device("cuda", rt_device.device_id)
-        self.gatherer = FrameGatherer(height, width, strip_rows, self.torch_device, group)
+        self.gatherer = FrameGatherer(height, width, strip_rows, self.torch_device, group, force_collective)
         g = self.gatherer
         rt_device.set_partition(g.rank, g.world, strip_rows)
         self.stream = torch.cuda.current_stream(self.torch_device)

@@ -1,6 +1,7 @@
 """GPU edge cases through the C-ABI: empty and degenerate scenes, size extremes, error behaviour,
 the concurrent random-texture thread (random_texture.rs:56-61)."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np

@@ -1,6 +1,7 @@
 """Full BASELINE sizes on the GPU: properties that need no reference frame (determinism, kernel-shape
 equivalence, partition invariance, padding invariance, checksum of segment totals) plus one complete
 1920x1080 frame against the oracle."""
+import os
 import zlib
 
 import numpy as np
@@ -125,3 +126,17 @@ def test_accumulation_converges_at_1080p(device):
             deltas.append(float(np.abs(img - prev).mean()))
         prev = img
     assert deltas[-1] < 0.35 * deltas[0]
+
+
+def test_rccl_pipeline_single_rank():
+    """tools/nccl_single.py: the N>1 composition (async RCCL gather, double-buffered strips, de-interleave)
+    through a world-size-1 nccl group on this GPU, frames bit-identical to plain rendering.  Own process so
+    the process group does not leak into the other tests."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_single.py")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "0 differing" in p.stdout
