@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tile-chunk", type=int, default=2)
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="consecutive 1-spp frames per kernel launch (rt_render_frames, 1..64); 0 = 8 per GPU of the job, "
+                         "so that a launch carries eight frames' worth of tiles whatever the partition")
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo = 1-GPU rehearsal via host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -73,6 +76,8 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if args.steps > 512:
         raise SystemExit("bench.py: --steps must be <= 512 (per-frame event ring)")
+    if not 0 <= args.batch <= 64:
+        raise SystemExit("bench.py: --batch must be 0 (auto) or 1..64")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -108,13 +113,26 @@ def main():
         from rsraytracingv3_amd.distributed import TileParallelRenderer
         tiles = TileParallelRenderer(dev, W, H, args.strip_rows)
 
-    def step(k):
-        if tiles is None:
-            conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
-            conn.frame_data.progressive_count = 0
-            conn.draw()
-        else:
-            tiles.render(conn, jit[k], 0)  # rank 0 gets frame k-1 assembled while frame k renders
+    # A step is one 1-spp frame of the progressive accumulation (frame k has progressive_count k, as in the
+    # reference's loop while the camera rests); --batch B > 1 submits B consecutive frames per launch.
+    B = args.batch if args.batch > 0 else min(64, 8 * world)
+
+    def run_frames(first, count):
+        """frames first .. first+count-1; returns the number of launches"""
+        k, launches = first, 0
+        while k < first + count:
+            n = min(B, first + count - k)
+            if tiles is not None:  # rank 0 gets the previous launch's image assembled while this one renders
+                tiles.render(conn, jit[k] if B == 1 else jit[k:k + n], k)
+            elif B == 1:
+                conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
+                conn.frame_data.progressive_count = k
+                conn.draw()
+            else:
+                conn.draw_frames(jit[k:k + n], k)
+            k += n
+            launches += 1
+        return launches
 
     def fence():
         if tiles is not None:
@@ -125,23 +143,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k)
+    run_frames(0, args.warmup)
     fence()
     t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        step(k)
+    launches = run_frames(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
 
     # per-launch totals and HIP-event kernel durations of the timed region
-    seg = np.zeros(args.steps, np.uint64)
-    rough = np.zeros(args.steps, np.uint64)
-    kms = np.zeros(args.steps, np.float32)
-    dev.call("rt_get_frame_history", args.steps, seg.ctypes.data_as(C.c_void_p), rough.ctypes.data_as(C.c_void_p),
+    seg = np.zeros(launches, np.uint64)
+    rough = np.zeros(launches, np.uint64)
+    kms = np.zeros(launches, np.float32)
+    dev.call("rt_get_frame_history", launches, seg.ctypes.data_as(C.c_void_p), rough.ctypes.data_as(C.c_void_p),
              kms.ctypes.data_as(C.c_void_p))
     st = dev.stats()
-    local = torch.tensor([elapsed, float(seg.sum()), float(rough.sum()), float(kms.sum()), float(st.last_pixels)],
+    frame_px = float(st.last_pixels) / max(int(st.last_batch), 1)  # this rank's pixels of one frame
+    local = torch.tensor([elapsed, float(seg.sum()), float(rough.sum()), float(kms.sum()), frame_px],
                          dtype=torch.float64, device="cuda")
     if world > 1:
         mx = local.clone()
@@ -159,11 +176,26 @@ def main():
 
     steps = args.steps
     value = total_seg / elapsed / 1e6
+    # for reference: the same frames submitted one per launch (the interactive, lowest-latency way)
+    single = None
+    if world == 1 and B > 1:
+        n1 = min(100, args.steps)
+        B, keep = 1, B
+        run_frames(0, 10)
+        fence()
+        t1 = time.perf_counter()
+        run_frames(args.warmup, n1)
+        fence()
+        dt1 = time.perf_counter() - t1
+        B = keep
+        seg1 = np.zeros(n1, np.uint64)
+        dev.call("rt_get_frame_history", n1, seg1.ctypes.data_as(C.c_void_p), None, None)
+        single = {"frames_per_launch": 1, "frames": n1, "ms_per_frame": round(dt1 / n1 * 1e3, 5),
+                  "mrays_per_s": round(float(seg1.sum()) / dt1 / 1e6, 2)}
     # roofline of the dominant (only) kernel, rank 0's launches
     k_sec = float(kms.sum()) * 1e-3
-    px_launch = float(st.last_pixels)
-    b_alg = algorithmic_bytes(px_launch * steps, float(seg.sum()), float(rough.sum()))
-    f_alg = algorithmic_flops(px_launch * steps, float(seg.sum()), n_objects)
+    b_alg = algorithmic_bytes(frame_px * steps, float(seg.sum()), float(rough.sum()))
+    f_alg = algorithmic_flops(frame_px * steps, float(seg.sum()), n_objects)
     achieved = b_alg / k_sec / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
@@ -192,6 +224,8 @@ def main():
             "partition": "row strips of %d, round-robin over %d GPU(s)%s" % (args.strip_rows, world,
                                                                           ", RCCL gather to rank 0" if world > 1 else ""),
             "kernel_variant": args.variant,
+            "frames_per_launch": B,
+            "one_frame_per_launch": single,
             "segments_per_pixel": round(total_seg / (float(W) * H * steps), 4),
             "mpixels_per_s": round(W * H * steps / elapsed / 1e6, 2),
         },
@@ -204,7 +238,8 @@ def main():
             "traffic": traffic,
             "kernel": {2: "render_persistent", 3: "render_blocks", -1: "auto (render_blocks at this size)"}.get(args.variant, "render_tiles"),
             "avg_launch_ms": round(float(kms.mean()), 5),
-            "alg_bytes_per_launch": round(b_alg / steps, 1),
+            "launches": launches,
+            "alg_bytes_per_launch": round(b_alg / launches, 1),
             "note": "VALU-bound path (SURVEY §8d): see 'valu' for the binding roofline",
         },
         "valu": {
@@ -212,7 +247,7 @@ def main():
             "peak": VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(f_alg / k_sec / 1e12 / VALU_PEAK_TFLOPS, 5),
-            "alg_flops_per_launch": round(f_alg / steps, 1),
+            "alg_flops_per_launch": round(f_alg / launches, 1),
             "kernel_mrays_per_s": round(float(seg.sum()) / k_sec / 1e6, 2),
             "scan_lane_occupancy": round(float(st.last_segments) / (64.0 * st.last_wave_iterations), 4)
             if st.last_wave_iterations else None,
@@ -230,14 +265,15 @@ def main():
         cfg = scene.config_bytes(W, H)
         oracle.render(objects, count, cfg, jit[args.warmup], 0, sky, rnd, rows=(rows[0], rows[0] + 8),
                       threads=threads, want_hits=False)  # warm the thread pool
-        cseg, cdt, frames, first_seg = 0, 0.0, 0, None
-        while cdt < 12.0 and frames < args.steps:  # a bounded sample: whole frames until ~12 s of wall time
+        cseg, cdt, frames, first_seg = 0, 0.0, 0, 0
+        first_n = min(B, args.steps)  # frames of the first timed launch
+        while (cdt < 12.0 or frames < first_n) and frames < args.steps:  # a bounded sample: whole frames, ~12 s of wall time
             k = args.warmup + frames
             c0 = time.perf_counter()
             fr = oracle.render(objects, count, cfg, jit[k], 0, sky, rnd, rows=rows, threads=threads, want_hits=False)
             cdt += time.perf_counter() - c0
             fs = int(fr.segments[rows[0]:rows[1]].sum())
-            first_seg = fs if first_seg is None else first_seg
+            first_seg += fs if frames < first_n else 0
             cseg += fs
             frames += 1
         out["cpu_baseline"] = {

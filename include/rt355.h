@@ -58,14 +58,14 @@ enum {
 
 typedef struct rt_stats {
   uint64_t frames;            /* rt_render calls completed                                  */
-  uint64_t last_segments;     /* ray segments (bounce-loop iterations) of the last frame    */
+  uint64_t last_segments;     /* ray segments (bounce-loop iterations) of the last launch   */
   uint64_t last_rough_hits;   /* segments of the last frame that drew random() (rough hit)  */
   uint64_t last_pixels;       /* pixels this context rendered in the last frame             */
   float last_kernel_ms;       /* HIP-event time of the last frame's render kernel           */
   uint32_t width, height;     /* full frame                                                 */
   uint32_t local_rows;        /* rows owned by this context under the current partition     */
   uint32_t object_count, sphere_count, plane_count;
-  uint32_t _pad;
+  uint32_t last_batch;        /* frames the last launch rendered (rt_render_frames; 1 for rt_render)  */
   uint64_t last_wave_iterations; /* variant 2: object scans executed by all waves (64 lanes each);
                                     last_segments / (64 * this) = lane occupancy of the scan */
   uint64_t last_cull_mismatches; /* RT_OPT_CULL = 2: primary rays whose culled scan disagreed with the
@@ -135,6 +135,15 @@ RT355_API int rt_set_outputs(rt_context *ctx, uint32_t out_flags);
  * which makes its output irreproducible).  Asynchronous: returns after the launch. */
 RT355_API int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progressive_count);
 RT355_API int rt_render_frame(rt_context *ctx, const void *framedata16); /* same, FrameData blob */
+/* n_frames (1..64) consecutive frames in ONE kernel launch: framedata16 = n_frames FrameData blobs
+ * (connection.rs:13-33), i.e. a jitter and a progressive_count per frame.  The target, its history and
+ * rt_read_* afterwards are bit-identical to n_frames rt_render_frame calls in that order with the
+ * random texture unchanged in between (the launch computes every frame's float sample, a second
+ * small kernel replays frag.hlsl:60-65 and the sRGB8 store frame by frame).  For progressive
+ * accumulation (app.rs:208-254 calls one frame per loop turn): a launch of several frames fills the
+ * GPU where one frame, or one rank's strips of it, cannot.  RT_OUT_SEGMENTS / RT_OUT_HITS describe a
+ * single frame and must be off when n_frames > 1. */
+RT355_API int rt_render_frames(rt_context *ctx, uint32_t n_frames, const void *framedata16);
 RT355_API int rt_sync(rt_context *ctx);
 
 /* `RenderTarget::update` hands the wgpu view to egui (render_target.rs:50-70); here the

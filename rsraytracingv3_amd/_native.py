@@ -31,7 +31,7 @@ class RtStats(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("last_segments", C.c_uint64), ("last_rough_hits", C.c_uint64),
                 ("last_pixels", C.c_uint64), ("last_kernel_ms", C.c_float), ("width", C.c_uint32),
                 ("height", C.c_uint32), ("local_rows", C.c_uint32), ("object_count", C.c_uint32),
-                ("sphere_count", C.c_uint32), ("plane_count", C.c_uint32), ("_pad", C.c_uint32),
+                ("sphere_count", C.c_uint32), ("plane_count", C.c_uint32), ("last_batch", C.c_uint32),
                 ("last_wave_iterations", C.c_uint64), ("last_cull_mismatches", C.c_uint64)]
 
 
@@ -60,6 +60,7 @@ SIGNATURES = {
     "rt_selftest_sqrt": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "rt_render": (_i, [_vp, _f, _f, _u32]),
     "rt_render_frame": (_i, [_vp, _vp]),
+    "rt_render_frames": (_i, [_vp, C.c_uint32, _vp]),
     "rt_sync": (_i, [_vp]),
     "rt_read_rgba8": (_i, [_vp, _vp, _sz]),
     "rt_read_rgbf32": (_i, [_vp, _vp, _sz]),

@@ -285,6 +285,21 @@ class Connection:
         """The render pass + history copy + submit of app.rs:219-250."""
         self.device.call("rt_render_frame", self.frame_data.as_bytes())
 
+    def draw_frames(self, jitters, first_progressive_count: Optional[int] = None):
+        """len(jitters) consecutive frames of the progressive accumulation in ONE launch
+        (rt_render_frames): frame i has jitter jitters[i] and progressive_count first + i, where
+        first defaults to this connection's current count.  Bit-identical to calling draw() once
+        per frame; leaves frame_data at the last frame of the batch."""
+        first = self.frame_data.progressive_count if first_progressive_count is None else int(first_progressive_count)
+        blob = bytearray()
+        for i, j in enumerate(jitters):
+            self.frame_data.jitter = (float(j[0]), float(j[1]))
+            self.frame_data.progressive_count = first + i
+            blob += self.frame_data.as_bytes()
+        if not blob:
+            return
+        self.device.call("rt_render_frames", len(blob) // FrameData.BUFFER_SIZE, bytes(blob))
+
 
 def render_scene(device: Device, connection: Connection, render_target: RenderTarget, scene: Scene,
                  jitter: Optional[Tuple[float, float]] = None):

@@ -26,6 +26,7 @@ namespace rt355 {
 constexpr uint32_t kTotalShards = 32;       // frame-total counters are sharded over this many 128 B lines
 constexpr uint32_t kTotalShardStride = 16;  // u64 words between shards (128 B)
 constexpr uint32_t kSphBatch = 8;  // sphere records consumed per scan-loop trip
+constexpr uint32_t kMaxBatch = 64;  // frames one launch can render (rt_render_frames)
 
 struct DeviceScene {
   const float4 *sph;
@@ -42,7 +43,12 @@ struct FrameParams {
   uint32_t width, height;      // full frame (Config.width/height, scene.rs:267-268)
   uint32_t reflection_limit;   // Config.reflection_limit
   uint32_t progressive_count;  // FrameData (connection.rs:13-16)
-  float jitter_x, jitter_y;
+  // Frames of this launch.  A batch is rendered as one image of `batch` frames stacked on top of each
+  // other, frame_tile_rows 8-row tile rows apart: the tile index decides the frame, the frame its
+  // jitter.  batch == 1 is the plain frame; batch > 1 writes float samples (rgbf32 only, opacity 1)
+  // that resolve_batch_kernel folds into the history in frame order.
+  uint32_t batch, frame_tile_rows;
+  float jitter[2 * kMaxBatch];  // {x, y} per frame
   float opacity, keep;         // 1/(progressive_count+1) and 1 - that (frag.hlsl:61-62)
   // pixel-independent part of create_ray (ray.hlsl:16-29), evaluated on the host
   f3 cam_pos, cam_right, cam_neg_up, top_left;
@@ -74,6 +80,22 @@ struct FrameParams {
   int cull_check;
 };
 
+// resolve_batch_kernel: folds a batch's float samples into the history, frame by frame
+struct ResolveParams {
+  const float *samples;     // [batch][frame_stride pixels][3]
+  uint32_t batch;
+  uint32_t pixels;          // local_rows * width
+  uint32_t frame_stride;    // pixels between frames in `samples`
+  uint32_t count[kMaxBatch];  // progressive_count of each frame
+  float opacity[kMaxBatch];   // 1 / (count + 1)
+  uint32_t *rgba8;
+  const uint32_t *hist_rgba8;
+  float *rgbf32;
+  float *hist_f32;
+  const float *srgb_lut;
+  int accum_mode;
+};
+
 // kernels (rt_kernels.hip)
 struct LaunchConfig {
   int variant;            // -1 auto; 0 tiles, LDS geometry; 1 tiles, global-memory geometry;
@@ -87,6 +109,7 @@ int persistent_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);
 int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream);
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream);
+int launch_resolve(const ResolveParams &rp, hipStream_t stream);
 int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned long long *masks, hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);
 int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream);

@@ -322,13 +322,14 @@ struct Path {
 };
 
 // fs_main up to the call of trace_ray_with_reflections (frag.hlsl:49-57, ray.hlsl:31-37).
-__device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, uint32_t lrow, Path &s) {
+// `frame`: which frame of the launch's batch (stacked frame_tile_rows tile rows apart in the outputs).
+__device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, uint32_t lrow, uint32_t frame, Path &s) {
   // local row -> global row of the round-robin strip partition
   const uint32_t y = ((lrow / fp.strip_rows) * fp.world + fp.rank) * fp.strip_rows + lrow % fp.strip_rows;
-  s.p = lrow * fp.width + x;
+  s.p = (frame * fp.frame_tile_rows * kTile + lrow) * fp.width + x;
   // D14: SV_POSITION.xy = pixel centre
-  const float pjx = (static_cast<float>(x) + 0.5f) + fp.jitter_x;
-  const float pjy = (static_cast<float>(y) + 0.5f) + fp.jitter_y;
+  const float pjx = (static_cast<float>(x) + 0.5f) + fp.jitter[2u * frame];
+  const float pjy = (static_cast<float>(y) + 0.5f) + fp.jitter[2u * frame + 1u];
   const float cjx = pjx / static_cast<float>(fp.width), cjy = pjy / static_cast<float>(fp.height);
   s.rng = Rng{42.0f, cjx, cjy};
   f3 pw = fma3(fp.cam_right, cjx * fp.vp_width, fp.top_left);
@@ -442,8 +443,9 @@ __device__ __forceinline__ void path_end(const FrameParams &fp, const Path &s) {
     }
   }
   const f3 mixed = fma3(result, fp.opacity, prev * fp.keep);
-  fp.rgba8[p] = srgb8_encode_spec(mixed.x) | (srgb8_encode_spec(mixed.y) << 8) |
-                (srgb8_encode_spec(mixed.z) << 16) | 0xff000000u;
+  if (fp.rgba8)  // null in the sample pass of a batch (resolve_batch_kernel encodes)
+    fp.rgba8[p] = srgb8_encode_spec(mixed.x) | (srgb8_encode_spec(mixed.y) << 8) |
+                  (srgb8_encode_spec(mixed.z) << 16) | 0xff000000u;
   if (fp.rgbf32) {
     fp.rgbf32[3 * p] = mixed.x;
     fp.rgbf32[3 * p + 1] = mixed.y;
@@ -484,6 +486,19 @@ __device__ __forceinline__ void add_totals(const FrameParams &fp, uint32_t seg, 
   }
 }
 
+// Tile index of the launch -> tile column / tile row inside its frame and the frame of the batch.
+struct TilePos {
+  uint32_t col, row, frame;
+};
+__device__ __forceinline__ TilePos tile_pos(const FrameParams &fp, uint32_t tile, uint32_t tiles_x) {
+  TilePos t;
+  const uint32_t stacked_row = tile / tiles_x;
+  t.col = tile - stacked_row * tiles_x;
+  t.frame = stacked_row / fp.frame_tile_rows;
+  t.row = stacked_row - t.frame * fp.frame_tile_rows;
+  return t;
+}
+
 template <bool GEOM_LDS>
 __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_sph[];
@@ -495,8 +510,9 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-  const uint32_t x = (wave % tiles_x) * kTile + (lane & 7u);
-  const uint32_t lrow = (wave / tiles_x) * kTile + (lane >> 3);
+  const TilePos tp = tile_pos(fp, wave, tiles_x);
+  const uint32_t x = tp.col * kTile + (lane & 7u);
+  const uint32_t lrow = tp.row * kTile + (lane >> 3);
   uint32_t seg = 0, rough = 0;
   Path s;
   s.p = 0;
@@ -504,15 +520,15 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
   s.rough = 0;
   s.o = s.d = s.energy = s.result = mk3(0.0f, 0.0f, 0.0f);
   s.rng = Rng{0.0f, 0.0f, 0.0f};
-  const bool valid = (x < fp.width) & (lrow < fp.local_rows);
+  const bool valid = (x < fp.width) & (lrow < fp.local_rows) & (tp.frame < fp.batch);
   bool alive = false;
   if (valid) {
-    path_begin(fp, x, lrow, s);
+    path_begin(fp, x, lrow, tp.frame, s);
     alive = fp.reflection_limit != 0u;
   }
   if (fp.tile_masks != nullptr && __builtin_amdgcn_ballot_w64(alive) != 0ull)
-    alive = path_step_wave<true>(sc, sph, fp, s, alive, fp.tile_masks + static_cast<size_t>(wave % tiles_x) * fp.mask_words,
-                                 fp.tile_masks + static_cast<size_t>(tiles_x + wave / tiles_x) * fp.mask_words);
+    alive = path_step_wave<true>(sc, sph, fp, s, alive, fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words,
+                                 fp.tile_masks + static_cast<size_t>(tiles_x + tp.row) * fp.mask_words);
   while (__builtin_amdgcn_ballot_w64(alive) != 0ull) alive = path_step_wave<true>(sc, sph, fp, s, alive);
   if (valid) {
     path_end<true>(fp, s);
@@ -541,8 +557,9 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
   const uint32_t tile = blockIdx.x * NW + wave;
-  const uint32_t x = (tile % tiles_x) * kTile + (lane & 7u);
-  const uint32_t lrow = (tile / tiles_x) * kTile + (lane >> 3);
+  const TilePos tp = tile_pos(fp, tile, tiles_x);
+  const uint32_t x = tp.col * kTile + (lane & 7u);
+  const uint32_t lrow = tp.row * kTile + (lane >> 3);
   Path s;
   s.p = 0;
   s.seg = 0;
@@ -551,17 +568,17 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   s.rng = Rng{0.0f, 0.0f, 0.0f};
   bool alive = false;
   uint32_t seg_total = 0, rough_total = 0, iters = 0;
-  if ((x < fp.width) & (lrow < fp.local_rows)) {
-    path_begin(fp, x, lrow, s);
+  if ((x < fp.width) & (lrow < fp.local_rows) & (tp.frame < fp.batch)) {
+    path_begin(fp, x, lrow, tp.frame, s);
     alive = fp.reflection_limit != 0u;
     if (!alive) path_end(fp, s);
   }
   uint32_t live_waves = NW;
   __syncthreads();  // sphere records staged
   const unsigned long long *primary_mask =
-      fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tile % tiles_x) * fp.mask_words : nullptr;
+      fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words : nullptr;
   const unsigned long long *primary_mask2 =
-      fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tiles_x + tile / tiles_x) * fp.mask_words : nullptr;
+      fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tiles_x + tp.row) * fp.mask_words : nullptr;
   // A finished path keeps its result in the lane's registers and is written out (sRGB encode +
   // stores, ~150 instructions) together with the other finished lanes when the lane is about to be
   // re-used or the wave ends, not one partial-wave call per bounce.
@@ -653,8 +670,7 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-  const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
-  const uint32_t n_tiles = tiles_x * tiles_y;
+  const uint32_t n_tiles = tiles_x * fp.frame_tile_rows * fp.batch;
   // Work distribution: the frame's tiles are cut into chunks of `tile_chunk` consecutive tiles;
   // chunk c belongs to shard c % 8, each shard has its own counter on its own 128-byte line, a
   // wave starts on the shard of its workgroup (workgroups are dealt round-robin over the 8 XCDs)
@@ -715,10 +731,11 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
         const bool needy = (need >> lane) & 1ull;
         const uint32_t k = tpos + below;
         if (needy && k < 64u) {
-          const uint32_t x = (tile % tiles_x) * kTile + (k & 7u);
-          const uint32_t lrow = (tile / tiles_x) * kTile + (k >> 3);
+          const TilePos tp = tile_pos(fp, tile, tiles_x);
+          const uint32_t x = tp.col * kTile + (k & 7u);
+          const uint32_t lrow = tp.row * kTile + (k >> 3);
           if ((x < fp.width) & (lrow < fp.local_rows)) {
-            path_begin(fp, x, lrow, s);
+            path_begin(fp, x, lrow, tp.frame, s);
             alive = fp.reflection_limit != 0u;
             if (!alive) path_end(fp, s);
           }
@@ -814,6 +831,51 @@ __global__ void __launch_bounds__(256) cull_slabs_kernel(DeviceScene sc, FramePa
   }
 }
 
+// Second pass of a batch launch (rt_render_frames): folds the batch's float samples into the history
+// in frame order, i.e. replays frag.hlsl:60-65 + the Rgba8UnormSrgb store once per frame exactly as
+// path_end would have done in `batch` separate launches (same expression, same quantisation of every
+// intermediate frame), and stores the state after the last frame.
+__global__ void __launch_bounds__(256) resolve_batch_kernel(ResolveParams rp) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= rp.pixels) return;
+  f3 prev = mk3(0.0f, 0.0f, 0.0f);
+  if (rp.count[0] != 0u) {
+    if (rp.accum_mode == 1) {
+      prev = mk3(rp.hist_f32[3 * static_cast<size_t>(p)], rp.hist_f32[3 * static_cast<size_t>(p) + 1],
+                 rp.hist_f32[3 * static_cast<size_t>(p) + 2]);
+    } else {
+      const uint32_t w = rp.hist_rgba8[p];
+      prev = mk3(rp.srgb_lut[w & 255u], rp.srgb_lut[(w >> 8) & 255u], rp.srgb_lut[(w >> 16) & 255u]);
+    }
+  }
+  f3 mixed = prev;
+  uint32_t texel = 0;
+  for (uint32_t f = 0; f < rp.batch; ++f) {
+    const size_t q = 3 * (static_cast<size_t>(f) * rp.frame_stride + p);
+    const f3 sample = mk3(rp.samples[q], rp.samples[q + 1], rp.samples[q + 2]);
+    if (rp.count[f] == 0u) prev = mk3(0.0f, 0.0f, 0.0f);  // path_end does not read the history then
+    const float opacity = rp.opacity[f];
+    const float keep = 1.0f - opacity;
+    mixed = fma3(sample, opacity, prev * keep);
+    texel = srgb8_encode_spec(mixed.x) | (srgb8_encode_spec(mixed.y) << 8) | (srgb8_encode_spec(mixed.z) << 16) |
+            0xff000000u;
+    prev = rp.accum_mode == 1 ? mixed
+                              : mk3(rp.srgb_lut[texel & 255u], rp.srgb_lut[(texel >> 8) & 255u],
+                                    rp.srgb_lut[(texel >> 16) & 255u]);
+  }
+  rp.rgba8[p] = texel;
+  if (rp.rgbf32) {
+    rp.rgbf32[3 * static_cast<size_t>(p)] = mixed.x;
+    rp.rgbf32[3 * static_cast<size_t>(p) + 1] = mixed.y;
+    rp.rgbf32[3 * static_cast<size_t>(p) + 2] = mixed.z;
+  }
+  if (rp.hist_f32 && rp.accum_mode == 1) {
+    rp.hist_f32[3 * static_cast<size_t>(p)] = mixed.x;
+    rp.hist_f32[3 * static_cast<size_t>(p) + 1] = mixed.y;
+    rp.hist_f32[3 * static_cast<size_t>(p) + 2] = mixed.z;
+  }
+}
+
 // Device-side refill of the random texture: the reference regenerates 600x600
 // uniform floats on a host thread every 4 ms and uploads them (random_texture.rs:56-75, ~360 MB/s of
 // PCIe); here texel k (row-major) is SplitMix64 output k+1 of `seed`, top 24 bits -> [0,1) on the
@@ -867,8 +929,10 @@ __global__ void sqrt_exhaustive_kernel(unsigned long long *mismatches) {
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream) {
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
   const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
-  const uint64_t tiles = static_cast<uint64_t>(tiles_x) * tiles_y;
+  if (fp.batch < 1u || fp.batch > kMaxBatch || fp.frame_tile_rows != tiles_y) return static_cast<int>(hipErrorInvalidValue);
+  const uint64_t tiles = static_cast<uint64_t>(tiles_x) * tiles_y * fp.batch;  // the batch as one stacked image
   if (tiles == 0) return 0;
+  if (tiles * (kTile * kTile) > 0xffffffffull) return static_cast<int>(hipErrorInvalidValue);  // pixel indices are 32-bit
   const size_t lds = static_cast<size_t>(sc.n_sph_pad) * sizeof(float4);
   int variant = lc.variant;
   if (variant < 0) {
@@ -879,7 +943,8 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     // primary-ray culling, which it cannot use; it stays selectable.
     variant = (sc.n_sph_pad > 128u || tiles < 24000ull) ? 0 : 3;
   }
-  if (variant == 3 && fp.reflection_limit > 63u) variant = 0;  // the packed path state keeps 6 bits of bounce count
+  // the packed path state keeps 6 bits of bounce count and 26 bits of pixel index
+  if (variant == 3 && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26))) variant = 0;
   // scenes whose sphere records do not fit a workgroup's default 64 KB of LDS are scanned from global memory
   if (lds + (variant == 3 ? kXchgPaths * 64u : 0u) > 60u * 1024u) variant = 1;
   if (variant == 2) {
@@ -902,6 +967,12 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
       hipLaunchKernelGGL(render_tiles<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, fp);
     }
   }
+  return static_cast<int>(hipGetLastError());
+}
+
+int launch_resolve(const ResolveParams &rp, hipStream_t stream) {
+  if (rp.pixels == 0 || rp.batch == 0) return 0;
+  hipLaunchKernelGGL(resolve_batch_kernel, dim3((rp.pixels + 255u) / 256u), dim3(256), 0, stream, rp);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -81,6 +81,8 @@ struct rt_context {
   unsigned long long *d_masks = nullptr;  // per-tile sphere masks of the primary-ray culling
   size_t masks_cap = 0;     // in 64-bit words
   bool masks_dirty = true;  // scene, size or partition changed since the masks were built
+  float *d_samples = nullptr;  // staging of a batch's float samples (rt_render_frames), batch x padded rows x W x 3
+  size_t samples_cap = 0;      // in floats
   rt_stats stats{};
   std::string error;
 };
@@ -254,6 +256,7 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_tile_counters);
   (void)hipFree(ctx->d_masks);
+  (void)hipFree(ctx->d_samples);
   (void)hipFree(ctx->d_lut);
   for (int i = 0; i < 2; ++i)
     if (ctx->rnd_last_use[i]) (void)hipEventDestroy(ctx->rnd_last_use[i]);
@@ -549,8 +552,16 @@ int rt_selftest_sqrt(rt_context *ctx, uint64_t *mismatches) {
   return RT_OK;
 }
 
-int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progressive_count) {
+// One launch of `batch` frames (1 = the plain rt_render): jitter {x, y} and progressive count per frame.
+static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, const uint32_t *counts) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (batch < 1u || batch > kMaxBatch)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_frames: %u frames, 1..%u allowed per call", batch, kMaxBatch);
+  if (batch > 1u && (ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS)))
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_frames: the segments / hits outputs describe one frame; "
+                                              "render batches with RT_OUT_RGBA8 | RT_OUT_RGBF32 only");
+  const float jitter_x = jitter[0], jitter_y = jitter[1];
+  const uint32_t progressive_count = counts[0];
   if (!ctx->d_hdri) return fail(ctx, RT_ERR_NOT_READY, "rt_render: no skybox (rt_set_skybox)");
   if (!ctx->have_scene) return fail(ctx, RT_ERR_NOT_READY, "rt_render: no scene (rt_set_scene)");
   if (!ctx->width) return fail(ctx, RT_ERR_NOT_READY, "rt_render: no target (rt_resize)");
@@ -577,8 +588,16 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   fp.height = ctx->height;
   fp.reflection_limit = ctx->config.reflection_limit;
   fp.progressive_count = progressive_count;
-  fp.jitter_x = jitter_x;
-  fp.jitter_y = jitter_y;
+  fp.batch = batch;
+  fp.frame_tile_rows = (ctx->local_rows + 7u) / 8u;
+  bool jitter_small = true;
+  for (uint32_t f = 0; f < batch; ++f) {
+    fp.jitter[2 * f] = jitter[2 * f];
+    fp.jitter[2 * f + 1] = jitter[2 * f + 1];
+    jitter_small = jitter_small && fabsf(jitter[2 * f]) <= 0.5f && fabsf(jitter[2 * f + 1]) <= 0.5f;
+  }
+  (void)jitter_x;
+  (void)jitter_y;
   fp.opacity = 1.0f / static_cast<float>(progressive_count + 1u);  // frag.hlsl:61
   fp.keep = 1.0f - fp.opacity;
   fp.cam_pos = ctx->cam_pos;
@@ -605,13 +624,50 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   fp.tile_counters = ctx->d_tile_counters + rt_context::kTileWords * static_cast<size_t>(slot);
   fp.srgb_lut = ctx->d_lut;
   fp.accum_mode = ctx->accum_mode;
+  // A batch renders float samples of all its frames (each as a frame of its own: count 0, opacity 1)
+  // into the staging buffer; resolve_batch_kernel then replays the history update frame by frame.
+  ResolveParams rp{};
+  if (batch > 1u) {
+    const size_t frame_stride = static_cast<size_t>(fp.frame_tile_rows) * 8u * ctx->width;
+    const size_t need = frame_stride * batch * 3u;
+    if (ctx->samples_cap < need) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      (void)hipFree(ctx->d_samples);
+      ctx->d_samples = nullptr;
+      ctx->samples_cap = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_samples, need * sizeof(float)));
+      ctx->samples_cap = need;
+    }
+    rp.samples = ctx->d_samples;
+    rp.batch = batch;
+    rp.pixels = ctx->local_rows * ctx->width;
+    rp.frame_stride = static_cast<uint32_t>(frame_stride);
+    for (uint32_t f = 0; f < batch; ++f) {
+      rp.count[f] = counts[f];
+      rp.opacity[f] = 1.0f / static_cast<float>(counts[f] + 1u);  // frag.hlsl:61
+    }
+    rp.rgba8 = fp.rgba8;
+    rp.hist_rgba8 = fp.hist_rgba8;
+    rp.rgbf32 = fp.rgbf32;
+    rp.hist_f32 = fp.hist_f32;
+    rp.srgb_lut = fp.srgb_lut;
+    rp.accum_mode = fp.accum_mode;
+    fp.progressive_count = 0;
+    fp.opacity = 1.0f;
+    fp.keep = 0.0f;
+    fp.rgba8 = nullptr;
+    fp.hist_rgba8 = nullptr;
+    fp.rgbf32 = ctx->d_samples;
+    fp.hist_f32 = nullptr;
+    fp.accum_mode = 0;
+  }
 
   // Primary-ray culling masks: rebuilt when the scene, the size or the partition changed; valid for
   // every jitter below half a pixel (larger jitters render without culling).
   fp.tile_masks = nullptr;
   fp.mask_words = 0;
   fp.cull_check = 0;
-  if (ctx->cull != 0 && ctx->scene.n_sph != 0 && fabsf(jitter_x) <= 0.5f && fabsf(jitter_y) <= 0.5f) {
+  if (ctx->cull != 0 && ctx->scene.n_sph != 0 && jitter_small) {
     const uint32_t words = (ctx->scene.n_sph + 63u) / 64u;
     const size_t tiles = static_cast<size_t>((ctx->width + 7) / 8) + ((ctx->local_rows + 7) / 8);  // column + row slabs
     if (ctx->masks_cap < tiles * words) {
@@ -654,9 +710,33 @@ int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progress
   RT_HIP(ctx, hipEventRecord(ctx->rnd_last_use[rnd], ctx->stream));
   ctx->rnd_used[rnd] = true;
   rnd_lock.unlock();
+  if (batch > 1u && launch_resolve(rp, ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "resolve launch failed");
   ctx->timing_valid = true;
   ctx->stats.frames += 1;
+  ctx->stats.last_batch = batch;
   return RT_OK;
+}
+
+int rt_render(rt_context *ctx, float jitter_x, float jitter_y, uint32_t progressive_count) {
+  const float jitter[2] = {jitter_x, jitter_y};
+  return render_frames(ctx, 1u, jitter, &progressive_count);
+}
+
+int rt_render_frames(rt_context *ctx, uint32_t n_frames, const void *framedata16) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!framedata16) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_frames: NULL FrameData");
+  if (n_frames < 1u || n_frames > kMaxBatch)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_frames: %u frames, 1..%u allowed per call", n_frames, kMaxBatch);
+  float jitter[2 * kMaxBatch];
+  uint32_t counts[kMaxBatch];
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    rt_wire_frame w;
+    std::memcpy(&w, static_cast<const unsigned char *>(framedata16) + sizeof w * f, sizeof w);
+    jitter[2 * f] = w.jitter[0];
+    jitter[2 * f + 1] = w.jitter[1];
+    counts[f] = w.progressive_count;
+  }
+  return render_frames(ctx, n_frames, jitter, counts);
 }
 
 int rt_render_frame(rt_context *ctx, const void *framedata16) {
@@ -733,7 +813,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
     ctx->stats.last_kernel_ms = ms;
   }
-  ctx->stats.last_pixels = static_cast<uint64_t>(ctx->local_rows) * ctx->width;
+  ctx->stats.last_pixels = static_cast<uint64_t>(ctx->local_rows) * ctx->width * (ctx->stats.last_batch ? ctx->stats.last_batch : 1u);
   ctx->stats.width = ctx->width;
   ctx->stats.height = ctx->height;
   ctx->stats.local_rows = ctx->local_rows;

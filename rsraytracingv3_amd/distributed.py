@@ -102,6 +102,7 @@ class TileParallelRenderer:
         self._ptrs = [b.data_ptr() for b in self.buffers]
         self._bind = rt_device._lib.rt_bind_outputs   # hot path: raw entry points, status checked inline
         self._render = rt_device._lib.rt_render
+        self._render_frames = rt_device._lib.rt_render_frames
         self.frame_index = 0
         self.pending = None  # (work handle | None, stacked buffer | None) of the gather in flight
 
@@ -116,15 +117,29 @@ class TileParallelRenderer:
         return self.gatherer.assemble(stacked) if self.gatherer.rank == 0 else None
 
     def render(self, connection, jitter, progressive_count: int = 0):
-        """Launch frame k; returns frame k-1 (rank 0) or None."""
+        """Launch frame k; returns frame k-1 (rank 0) or None.  ``jitter`` is one (x, y) pair, or a
+        sequence of n pairs: then n consecutive frames of the accumulation (counts progressive_count,
+        +1, ...) are rendered in ONE launch (rt_render_frames) and gathered once, after the last —
+        a rank's strips of a single frame are too little work to fill a GPU."""
         k = self.frame_index & 1
         buf = self.buffers[k]
         rc = self._bind(self.rt.handle, self._ptrs[k], self._ptrs[k ^ 1], None)
-        if rc == 0:
-            rc = self._render(self.rt.handle, float(jitter[0]), float(jitter[1]), progressive_count)
+        jit = np.asarray(jitter, dtype=np.float32)
+        if jit.ndim == 1:
+            if rc == 0:
+                rc = self._render(self.rt.handle, float(jit[0]), float(jit[1]), progressive_count)
+            last = (float(jit[0]), float(jit[1]), progressive_count)
+        else:
+            n = jit.shape[0]
+            blob = np.zeros((n, 4), dtype=np.uint32)  # FrameData: jitter f32 x2, progressive_count u32, pad
+            blob[:, :2] = jit.view(np.uint32)
+            blob[:, 2] = np.arange(progressive_count, progressive_count + n, dtype=np.uint32)
+            if rc == 0:
+                rc = self._render_frames(self.rt.handle, n, blob.ctypes.data)
+            last = (float(jit[-1, 0]), float(jit[-1, 1]), progressive_count + n - 1)
         self.rt._check(rc, "rt_render")
-        connection.frame_data.jitter = (float(jitter[0]), float(jitter[1]))
-        connection.frame_data.progressive_count = progressive_count
+        connection.frame_data.jitter = last[:2]
+        connection.frame_data.progressive_count = last[2]
         self.frame_index += 1
         previous_frame = self._collect()
         stacked, work = self.gatherer.gather(buf, async_op=True)

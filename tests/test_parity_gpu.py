@@ -315,3 +315,90 @@ def test_device_math_bitwise(device):
     a = rs.normal(size=n).astype(np.float32)
     b = rs.normal(size=n).astype(np.float32)
     assert np.array_equal(dev_binary(2, a, b).view(np.uint32), (a / b).view(np.uint32)), "device divide not IEEE"
+
+
+def _batch_vs_sequential(device, scene, size, sky, rnd, jitters, first_pc, accum, variant, partition=(0, 1, 8)):
+    """Renders len(jitters) frames once as separate launches and once as ONE rt_render_frames launch from the
+    same starting history; returns the two (rgba8, rgbf32) states after the last frame plus the stats."""
+    device.set_partition(*partition)
+    device.set_accum_mode(accum)
+    device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
+    device.set_variant(variant)
+    target = RenderTarget.new(device, size)
+    rt = RandomTexture(device)
+    rt.write(rnd)
+    conn = Connection(scene, device, sky, rt, max_objects="live")
+    conn.update_buffers(size, scene, (0.0, 0.0))
+    states = []
+    for mode in ("sequential", "batch"):
+        # common starting history: two plain frames (counts 0, 1) so that first_pc > 0 mixes with real texels
+        for k, j in enumerate([(0.11, 0.07), (-0.2, 0.3)]):
+            conn.frame_data.jitter, conn.frame_data.progressive_count = j, k
+            conn.draw()
+        if mode == "sequential":
+            for i, j in enumerate(jitters):
+                conn.frame_data.jitter, conn.frame_data.progressive_count = (float(j[0]), float(j[1])), first_pc + i
+                conn.draw()
+        else:
+            conn.draw_frames(jitters, first_pc)
+        device.sync()
+        states.append((target.read_rgba8().copy(), target.read_rgbf32().copy()))
+    return states, device.stats()
+
+
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("accum", [N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32])
+def test_batch_launch_equals_sequential_frames(device, variant, accum):
+    """rt_render_frames: 5 frames in one launch == 5 rt_render_frame calls, texels and floats bit for bit."""
+    scene = cases.headline_scene(6)
+    sky, rnd = cases.inputs(256, 128)
+    jit = [(0.1, -0.2), (-0.33, 0.27), (0.45, 0.05), (-0.49, -0.49), (0.0, 0.31)]
+    (seq, bat), st = _batch_vs_sequential(device, scene, (203, 101), sky, rnd, jit, 2, accum, variant)
+    assert st.last_batch == 5 and st.last_pixels == 5 * 203 * 101
+    assert np.array_equal(seq[0], bat[0])
+    assert np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32))
+
+
+def test_batch_launch_restarting_accumulation_and_oracle(device):
+    """A batch whose first frame has progressive_count 0 (history ignored) against the oracle's frame chain,
+    under a 3-way strip partition (rank 1's rows)."""
+    scene = cases.headline_scene(4)
+    sky, rnd = cases.inputs(256, 128)
+    size = (96, 80)
+    jit = [(0.25, 0.25), (-0.25, 0.1), (0.4, -0.4)]
+    (seq, bat), _ = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_SRGB8, -1, partition=(1, 3, 8))
+    assert np.array_equal(seq[0], bat[0]) and np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32))
+    history = None
+    for k in range(3):
+        ref = oracle.render(scene.live_object_bytes(), len(scene.objects), scene.config_bytes(*size), jit[k], k, sky, rnd,
+                            history_rgba8=history)
+        history = ref.rgba8
+    from rsraytracingv3_amd.partition import local_row_indices
+    rows = local_row_indices(size[1], 1, 3, 8)
+    assert np.array_equal(bat[0], ref.rgba8[rows])
+    assert np.array_equal(bat[1].view(np.uint32), ref.rgbf32[rows].view(np.uint32))
+
+
+def test_batch_launch_limits(device):
+    """64 frames is the most one launch takes; the single-frame debug outputs must be off."""
+    scene = cases.config1_scene()
+    sky, rnd = cases.inputs(64, 32)
+    device.set_partition(0, 1, 8)
+    device.set_outputs(N.RT_OUT_RGBA8)
+    target = RenderTarget.new(device, (64, 48))
+    rt = RandomTexture(device)
+    rt.write(rnd)
+    conn = Connection(scene, device, sky, rt)
+    conn.update_buffers((64, 48), scene, (0.0, 0.0))
+    conn.draw_frames([(0.0, 0.0)] * 64, 0)
+    device.sync()
+    assert device.stats().last_batch == 64
+    with pytest.raises(N.RtError):
+        conn.draw_frames([(0.0, 0.0)] * 65, 0)
+    device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_SEGMENTS)
+    RenderTarget.new(device, (64, 48))
+    with pytest.raises(N.RtError):
+        conn.draw_frames([(0.0, 0.0)] * 2, 0)
+    conn.draw_frames([(0.1, 0.1)], 0)  # a batch of one is a plain frame, debug outputs allowed
+    device.sync()
+    assert target.read_segments().shape == (48, 64)

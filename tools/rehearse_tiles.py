@@ -6,7 +6,8 @@
 
 Every rank renders its row strips through the C-ABI (all ranks may share one GPU with
 --backend gloo), rank 0 gathers, de-interleaves and compares the frame bit-for-bit with the CPU
-oracle, for three pipelined frames (double-buffered send tensors)."""
+oracle, for three pipelined frames (double-buffered send tensors) and then for two launches of five
+progressive frames each (rt_render_frames; one gather per launch, history = the previous launch)."""
 import argparse
 import os
 import sys
@@ -57,9 +58,28 @@ def main():
     last = tiles.finish()
     if last is not None:
         frames.append((2, last.clone()))
+    jit2 = synth.jitter_sequence(11, 10)
+    batches = []
+    for b in range(2):
+        out = tiles.render(conn, jit2[5 * b:5 * b + 5], 5 * b)
+        if out is not None:
+            batches.append(out.clone())
+    last = tiles.finish()
+    if last is not None:
+        batches.append(last.clone())
     ok = True
     if rank == 0:
         objects = scene.as_bytes(W, H)[0]
+        history = None
+        for k in range(10):
+            ref = oracle.render(objects, 80, scene.config_bytes(W, H), jit2[k], k, sky, rnd, history_rgba8=history,
+                                threads=8, want_hits=False)
+            history = ref.rgba8
+            if k % 5 == 4:
+                got = batches[k // 5].cpu().numpy().view(np.uint8).reshape(H, W, 4)
+                same = np.array_equal(got, ref.rgba8)
+                print("progressive frames %d..%d in one launch: %s" % (k - 4, k, "bit-identical to the oracle" if same else "MISMATCH"))
+                ok &= same
         for k, frame in frames:
             ref = oracle.render(objects, 80, scene.config_bytes(W, H), jit[k], 0, sky, rnd, threads=8, want_hits=False)
             got = frame.cpu().numpy().view(np.uint8).reshape(H, W, 4)
