@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive 1-spp frames per kernel launch (rt_render_frames, 1..64); 0 = 8 per GPU of the job, "
                          "so that a launch carries eight frames' worth of tiles whatever the partition")
+    ap.add_argument("--single-frame-reference", action="store_true",
+                    help="also time 100 frames submitted one per launch (reported in config.one_frame_per_launch)")
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo = 1-GPU rehearsal via host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,7 +95,7 @@ def main():
     n_objects = len(scene.objects) if args.slots == 0 else args.slots
     sky = synth.procedural_skybox(args.sky, args.sky // 2)
     rnd = synth.random_texture(1)
-    jit = synth.jitter_sequence(42, args.steps + args.warmup)
+    jit = synth.jitter_sequence(42, args.steps + args.warmup + 64)
 
     dev = Device(local_rank)
     dev.set_outputs(N.RT_OUT_RGBA8)
@@ -143,10 +145,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    run_frames(0, args.warmup)
+    # warm-up in whole launches (W rounded up to a multiple of the batch), so that every launch a profiler
+    # sees carries the same number of frames as the timed ones
+    warm_frames = -(-args.warmup // B) * B
+    run_frames(0, warm_frames)
     fence()
     t0 = time.perf_counter()
-    launches = run_frames(args.warmup, args.steps)
+    launches = run_frames(warm_frames, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -178,13 +183,13 @@ def main():
     value = total_seg / elapsed / 1e6
     # for reference: the same frames submitted one per launch (the interactive, lowest-latency way)
     single = None
-    if world == 1 and B > 1:
+    if world == 1 and B > 1 and args.single_frame_reference:
         n1 = min(100, args.steps)
         B, keep = 1, B
         run_frames(0, 10)
         fence()
         t1 = time.perf_counter()
-        run_frames(args.warmup, n1)
+        run_frames(warm_frames, n1)
         fence()
         dt1 = time.perf_counter() - t1
         B = keep
@@ -268,7 +273,7 @@ def main():
         cseg, cdt, frames, first_seg = 0, 0.0, 0, 0
         first_n = min(B, args.steps)  # frames of the first timed launch
         while (cdt < 12.0 or frames < first_n) and frames < args.steps:  # a bounded sample: whole frames, ~12 s of wall time
-            k = args.warmup + frames
+            k = warm_frames + frames
             c0 = time.perf_counter()
             fr = oracle.render(objects, count, cfg, jit[k], 0, sky, rnd, rows=rows, threads=threads, want_hits=False)
             cdt += time.perf_counter() - c0
