@@ -98,6 +98,18 @@ RT355_API int rt_set_skybox(rt_context *ctx, uint32_t width, uint32_t height, co
 /* `RandomTexture::write` (src/gpu/random_texture.rs:78-101): R32F noise texture the
  * shader's random() indexes (src/shaders/random.hlsl:4-11).  Thread-safe against
  * every other call; a frame sees either the old or the new texture, never a mix. */
+/* `Connection::load_image` + `load_hdri` for the reference's asset format (connection.rs:154-215; `image`
+ * 0.25.1 / `exr` 1.72.0 per Cargo.lock): read a single-part scan-line OpenEXR file (compression NONE,
+ * RLE, ZIPS, ZIP or PIZ; HALF / FLOAT / UINT channels R, G, B and optionally A) into RGBA32F, alpha 1
+ * where the file has none, rows top to bottom of the display window.  Host code only (usable without a
+ * GPU).  *out_rgba32f is released with rt_exr_free.  Errors: RT_ERR_INVALID_ARGUMENT with the text in
+ * rt_exr_last_error() (per thread), worded like the reference's ("Can't find image: ...", "Image
+ * invalid format: ...").  rt_set_skybox_exr = read + rt_set_skybox. */
+RT355_API int rt_exr_read_rgba32f(const char *path, uint32_t *out_width, uint32_t *out_height, float **out_rgba32f);
+RT355_API void rt_exr_free(float *rgba32f);
+RT355_API const char *rt_exr_last_error(void);
+RT355_API int rt_set_skybox_exr(rt_context *ctx, const char *path);
+
 RT355_API int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float *r32f);
 
 /* Device-side replacement of the reference's generator thread (`RandomTexture::generate_data` +

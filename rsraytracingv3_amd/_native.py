@@ -47,6 +47,10 @@ SIGNATURES = {
     "rt_create": (_i, [_i, C.POINTER(_vp)]),
     "rt_destroy": (_i, [_vp]),
     "rt_set_skybox": (_i, [_vp, _u32, _u32, _vp]),
+    "rt_exr_read_rgba32f": (_i, [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_float))]),
+    "rt_exr_free": (None, [C.POINTER(C.c_float)]),
+    "rt_exr_last_error": (C.c_char_p, []),
+    "rt_set_skybox_exr": (_i, [_vp, C.c_char_p]),
     "rt_set_random": (_i, [_vp, _u32, _u32, _vp]),
     "rt_generate_random": (_i, [_vp, _u32, _u32, C.c_uint64]),
     "rt_read_random": (_i, [_vp, _vp, _sz]),

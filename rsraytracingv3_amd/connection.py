@@ -21,6 +21,7 @@ explicit inputs (seeded generators by default) instead of unseeded process-globa
 from __future__ import annotations
 
 import copy
+import os
 import ctypes as C
 import struct
 import threading
@@ -248,8 +249,29 @@ class Connection:
         self.load_hdri(skybox)
         self.random_texture = random_texture or RandomTexture.start(device)
 
-    def load_hdri(self, skybox: np.ndarray):
-        """connection.rs:176-215 — (H, W, 4) float32, row 0 = top."""
+    @staticmethod
+    def load_image(file_name: str):
+        """connection.rs:154-162 — decode an OpenEXR file to ((width, height), (H, W, 4) float32), alpha 1
+        where the file has none (``into_rgba32f``).  Host code of the C-ABI library (rt_exr_read_rgba32f):
+        single-part scan-line files, NONE / RLE / ZIPS / ZIP / PIZ; error texts as the reference words them."""
+        from . import _native
+        lib = _native.load()
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        data = C.POINTER(C.c_float)()
+        rc = lib.rt_exr_read_rgba32f(os.fsencode(file_name), C.byref(w), C.byref(h), C.byref(data))
+        if rc != 0:
+            raise _native.RtError(rc, "rt_exr_read_rgba32f", (lib.rt_exr_last_error() or b"").decode(errors="replace"))
+        try:
+            arr = np.ctypeslib.as_array(data, shape=(h.value, w.value, 4)).copy()
+        finally:
+            lib.rt_exr_free(data)
+        return (w.value, h.value), arr
+
+    def load_hdri(self, skybox):
+        """connection.rs:176-215 — (H, W, 4) float32, row 0 = top, or the path of an .exr file (the
+        reference reads ./assets/table_mountain_1_8k.exr)."""
+        if isinstance(skybox, (str, bytes, os.PathLike)):
+            skybox = self.load_image(os.fspath(skybox))[1]
         skybox = np.ascontiguousarray(skybox, np.float32)
         if skybox.ndim != 3 or skybox.shape[2] != 4:
             raise ValueError("skybox must be (H, W, 4) float32")

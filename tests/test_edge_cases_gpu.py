@@ -276,3 +276,32 @@ def test_differential_fuzz_against_oracle():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(cases=120, first=10_000) == 0
+
+
+def test_skybox_from_an_exr_file(device, tmp_path):
+    """Connection.load_hdri with a path (connection.rs:176-215 reads ./assets/table_mountain_1_8k.exr) and
+    rt_set_skybox_exr: the frame equals the one rendered from the decoded array."""
+    import exr_writer as X
+    sky = synth.procedural_skybox(128, 64)
+    path = str(tmp_path / "sky.exr")
+    X.write_exr(path, {"R": (sky[..., 0], "half"), "G": (sky[..., 1], "half"), "B": (sky[..., 2], "half")}, X.PIZ)
+    (w, h), decoded = Connection.load_image(path)
+    assert (w, h) == (128, 64) and np.array_equal(decoded[..., :3], sky[..., :3].astype(np.float16).astype(np.float32))
+    scene = cases.headline_scene(4)
+    rnd = synth.random_texture(2)
+    frames = []
+    for mode, source in (("array", decoded), ("path", path), ("c-abi", decoded)):
+        device.set_partition(0, 1, 8)
+        device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
+        target = RenderTarget.new(device, (96, 64))
+        rt = RandomTexture(device)
+        rt.write(rnd)
+        conn = Connection(scene, device, source, rt)
+        if mode == "c-abi":
+            device.call("rt_set_skybox", 1, 1, np.zeros(4, np.float32).ctypes.data_as(C.c_void_p))  # something else first
+            device.call("rt_set_skybox_exr", path.encode())
+        render_scene(device, conn, target, scene, (0.2, -0.3))
+        device.sync()
+        frames.append(target.read_rgbf32().copy())
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))

@@ -1,0 +1,132 @@
+"""The OpenEXR skybox reader (rt_exr_read_rgba32f, Connection.load_image — connection.rs:154-162) against
+files written by tests/exr_writer.py: every supported compression, HALF / FLOAT / UINT channels, both PIZ
+wavelet modes, windows, line orders, raw-stored chunks, alpha handling and the reference's error texts.
+Host code only — runs without a GPU.  PARITY UNPINNED for files of other EXR writers (none exists here)."""
+import numpy as np
+import pytest
+
+import exr_writer as X
+from rsraytracingv3_amd import Connection
+from rsraytracingv3_amd import _native as N
+
+
+def _image(h, w, seed, smooth=True):
+    rs = np.random.RandomState(seed)
+    if smooth:  # gradients + a few bright spots, like a panorama: compressible, many distinct halfs
+        y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+        base = np.stack([0.2 + x / w, 0.1 + y / h, 0.5 + 0.25 * np.sin(x / 7.0) * np.cos(y / 5.0)], -1)
+        base[rs.randint(0, h, 5), rs.randint(0, w, 5)] *= 900.0
+        return base.astype(np.float32)
+    return np.exp(rs.uniform(-8, 8, (h, w, 3))).astype(np.float32)
+
+
+def _expected(rgb, typ, alpha=None):
+    h, w, _ = rgb.shape
+    out = np.ones((h, w, 4), np.float32)
+    for k in range(3):
+        out[..., k] = rgb[..., k].astype(X.NP_TYPE[typ]).astype(np.float32)
+    if alpha is not None:
+        out[..., 3] = alpha.astype(np.float16).astype(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("compression", [X.NONE, X.RLE, X.ZIPS, X.ZIP, X.PIZ])
+@pytest.mark.parametrize("typ", ["half", "float"])
+def test_round_trip_every_compression(tmp_path, compression, typ):
+    rgb = _image(45, 70, 1)  # 45 rows: a ragged last chunk for ZIP (16) and PIZ (32)
+    path = str(tmp_path / "a.exr")
+    X.write_exr(path, {"R": (rgb[..., 0], typ), "G": (rgb[..., 1], typ), "B": (rgb[..., 2], typ)}, compression)
+    (w, h), got = Connection.load_image(path)
+    assert (w, h) == (70, 45) and got.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), _expected(rgb, typ).view(np.uint32))
+
+
+def test_piz_16_bit_wavelet_mode_and_alpha(tmp_path):
+    """> 16384 distinct half values in a chunk switch PIZ to its 16-bit wavelet (wdec16); alpha is kept."""
+    rgb = _image(64, 400, 2, smooth=False)
+    alpha = np.random.RandomState(3).uniform(0, 1, (64, 400)).astype(np.float32)
+    path = str(tmp_path / "b.exr")
+    chans = {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "half"), "B": (rgb[..., 2], "half"), "A": (alpha, "half")}
+    X.write_exr(path, chans, X.PIZ)
+    block = np.stack([rgb[:32, :, k] for k in range(3)] + [alpha[:32]]).astype(np.float16).view(np.uint16)
+    assert len(np.unique(block)) > 16384  # the case is what it claims to be
+    _, got = Connection.load_image(path)
+    assert np.array_equal(got.view(np.uint32), _expected(rgb, "half", alpha).view(np.uint32))
+
+
+def test_piz_flat_and_tiny_images(tmp_path):
+    """Runs (the Huffman run-length escape), a constant image (empty value bitmap) and sizes below the wavelet's
+    smallest step."""
+    for i, (h, w, fill) in enumerate([(40, 50, 0.5), (33, 20, 0.0), (1, 1, 2.0), (2, 3, 1.5), (5, 1, 0.25)]):
+        rgb = np.full((h, w, 3), fill, np.float32)
+        if h > 8:
+            rgb[3:6, 4:9, 1] = 7.0
+        path = str(tmp_path / ("c%d.exr" % i))
+        X.write_exr(path, {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "half")}, X.PIZ)
+        _, got = Connection.load_image(path)
+        want = np.ones((h, w, 4), np.float32)
+        want[..., :3] = rgb
+        assert np.array_equal(got, want), (h, w)
+
+
+def test_uint_channels_extra_channels_and_line_order(tmp_path):
+    rs = np.random.RandomState(5)
+    rgb = rs.randint(0, 1 << 20, (37, 29, 3)).astype(np.uint32)
+    z = rs.uniform(0, 100, (37, 29)).astype(np.float32)
+    path = str(tmp_path / "d.exr")
+    X.write_exr(path, {"R": (rgb[..., 0], "uint"), "G": (rgb[..., 1], "uint"), "B": (rgb[..., 2], "uint"), "Z": (z, "float")},
+                X.ZIP, decreasing_y=True)
+    _, got = Connection.load_image(path)
+    want = np.ones((37, 29, 4), np.float32)
+    want[..., :3] = rgb.astype(np.float32)
+    assert np.array_equal(got, want)
+
+
+def test_data_window_inside_display_window(tmp_path):
+    rgb = _image(20, 30, 7)
+    path = str(tmp_path / "e.exr")
+    X.write_exr(path, {"R": (rgb[..., 0], "float"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "float")}, X.ZIPS,
+                display_window=(0, 0, 39, 31), data_origin=(6, 9))
+    (w, h), got = Connection.load_image(path)
+    assert (w, h) == (40, 32)
+    want = np.zeros((32, 40, 4), np.float32)
+    want[9:29, 6:36, :3] = rgb
+    want[9:29, 6:36, 3] = 1.0
+    assert np.array_equal(got, want)
+
+
+def test_chunks_stored_raw_when_compression_does_not_help(tmp_path):
+    rgb = _image(35, 33, 9, smooth=False)
+    for comp in (X.RLE, X.ZIP, X.PIZ):
+        path = str(tmp_path / ("f%d.exr" % comp))
+        X.write_exr(path, {"R": (rgb[..., 0], "float"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "float")}, comp,
+                    force_raw_chunks=True)
+        _, got = Connection.load_image(path)
+        assert np.array_equal(got[..., :3], rgb)
+
+
+def test_error_texts_follow_the_reference(tmp_path):
+    with pytest.raises(N.RtError, match="Can't find image"):  # connection.rs:156
+        Connection.load_image(str(tmp_path / "missing.exr"))
+    bad = tmp_path / "bad.exr"
+    bad.write_bytes(b"not an exr file at all")
+    with pytest.raises(N.RtError, match="Image invalid format"):  # connection.rs:159
+        Connection.load_image(str(bad))
+    rgb = _image(8, 8, 1)
+    path = str(tmp_path / "g.exr")
+    X.write_exr(path, {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "half")}, X.ZIP)
+    with pytest.raises(N.RtError, match="no R, G, B"):
+        Connection.load_image(path)
+    X.write_exr(path, {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "half"), "B": (rgb[..., 2], "half")}, X.ZIP)
+    data = bytearray(open(path, "rb").read())
+    k = data.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
+    data[k] = 5  # PXR24
+    open(path, "wb").write(bytes(data))
+    with pytest.raises(N.RtError, match="PXR24 is not supported"):
+        Connection.load_image(path)
+    truncated = bytes(data[:len(data) // 2])
+    data[k] = 3
+    open(path, "wb").write(bytes(data[:len(data) - 40]))
+    with pytest.raises(N.RtError, match="Image invalid format"):
+        Connection.load_image(path)
+    assert truncated
