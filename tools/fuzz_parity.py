@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Differential fuzzing of the HIP path against the CPU oracle: random scenes (overlapping spheres,
+"""Differential fuzzing of the HIP path against the CPU oracle (single frames, and every second case a
+multi-frame launch against the oracle frame chain): random scenes (overlapping spheres,
 tiny and huge radii, spheres around the camera, several planes, mirror / rough / emissive materials),
 random cameras, sizes, bounce limits, jitters, kernel shapes; every frame must be bit-identical and the
 in-kernel culling self-check must stay at zero.   python tools/fuzz_parity.py [cases] [first_seed]"""
@@ -76,6 +77,26 @@ def run(cases=100, first=0):
               and np.array_equal(target.read_segments(), ref.segments)
               and np.array_equal(target.read_hits(scene.reflection_limit), ref.hits)
               and st.last_cull_mismatches == 0 and st.last_segments == int(ref.segments.sum()))
+        if ok and seed % 2 == 0:  # several frames in one launch against the oracle's frame chain
+            rs = np.random.RandomState(seed + 77)
+            nf, pc0, accum = int(rs.randint(2, 7)), int(rs.choice([0, 0, 5])), int(rs.choice([0, 1]))
+            jit = rs.uniform(-0.495, 0.495, (nf, 2)).astype(np.float32)
+            dev.set_accum_mode(accum)
+            dev.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
+            target = RenderTarget.new(dev, size)
+            conn.draw_frames(jit, pc0)
+            dev.sync()
+            hist8 = np.zeros((h, w, 4), np.uint8) if accum == 0 else None
+            histf = np.zeros((h, w, 3), np.float32) if accum == 1 else None
+            for k in range(nf):
+                ref = oracle.render(objects, count, scene.config_bytes(w, h), (float(jit[k, 0]), float(jit[k, 1])), pc0 + k,
+                                    sky, rnd, history_rgba8=hist8, history_f32=histf, accum_mode=accum, threads=8,
+                                    want_hits=False)
+                hist8, histf = (ref.rgba8, None) if accum == 0 else (None, ref.rgbf32)
+            ok = (np.array_equal(target.read_rgba8(), ref.rgba8)
+                  and np.array_equal(target.read_rgbf32().view(np.uint32), ref.rgbf32.view(np.uint32)))
+            if not ok:
+                print("  (in the %d-frame launch, first count %d, accum %d)" % (nf, pc0, accum), flush=True)
         if not ok:
             bad += 1
             print("MISMATCH seed %d: %d objects, size %s, R %d, variant %d, slots %s, cull mismatches %d"
