@@ -84,6 +84,23 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels carry their own libamdhip64/libhsa-runtime64; a process
+    that first loads librt355.so (which would pull in /opt/rocm's copy) and then imports torch ends up with
+    two runtimes, and the second one finds no GPU ("No HIP GPUs are available").  When torch is installed,
+    its copy is loaded first — without importing torch — so both sides share it, whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    candidate = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(candidate):
+        C.CDLL(candidate, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load ``librt355.so``; raises (never falls back) when it is missing."""
     global _lib
@@ -93,6 +110,7 @@ def load():
                 "rt355: %s not found — the HIP extension is not built.  Run "
                 "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C rsraytracingv3_amd/csrc`. "
                 "There is no CPU fallback." % LIB_PATH)
+        _preload_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -61,3 +61,22 @@ def test_product_package_never_touches_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in text and "from oracle" not in text, f
                 assert "rt_oracle" not in text and "librt_oracle" not in text, f
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """librt355.so and PyTorch must share ONE HIP/HSA runtime in a process: with two copies mapped the second
+    one finds no GPU.  _native.load() therefore loads torch's bundled runtime first (without importing torch)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from rsraytracingv3_amd import _native\n"
+        "%s\n"
+        "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "print(len(libs), libs)\n"
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for order in ("_native.load(); import torch", "import torch; _native.load()"):
+        out = subprocess.run([sys.executable, "-c", code % (root, order)], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-1500:]
+        assert out.stdout.split()[0] == "1", "%s -> %s" % (order, out.stdout)
