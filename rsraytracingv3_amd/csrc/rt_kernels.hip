@@ -184,7 +184,7 @@ __device__ __forceinline__ SphereHit scan_spheres(const DeviceScene &sc, const f
   return SphereHit{best_key, slot};
 }
 
-// Wave-cooperative sphere scan for waves with few live rays (<= 16 of 64 lanes): G = 4, 8 or 16
+// Wave-cooperative sphere scan for waves with few live rays (<= 32 of 64 lanes): G = 2, 4, 8 or 16
 // lanes work for one ray, each testing every G-th sphere, and the closest hit is selected across the
 // G lanes with wavefront cross-lane operations — a lexicographic (key, slot) min over xor-butterfly
 // partners, which is exactly the reference's "strict '<' in ascending index" rule (App. B D10).
@@ -194,7 +194,7 @@ __device__ __forceinline__ SphereHit scan_spheres(const DeviceScene &sc, const f
 __device__ __forceinline__ SphereHit scan_spheres_coop(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d,
                                                        bool alive, unsigned long long live, uint32_t n_live_rays) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t shift = n_live_rays <= 4u ? 4u : (n_live_rays <= 8u ? 3u : 2u);  // log2(G), wave-uniform
+  const uint32_t shift = n_live_rays <= 4u ? 4u : (n_live_rays <= 8u ? 3u : (n_live_rays <= 16u ? 2u : 1u));  // log2(G), wave-uniform
   const uint32_t G = 1u << shift;
   // rank of each live lane among the live lanes; dead lanes get the ranks after them, so that
   // "rank -> lane" is a permutation of 0..63 and ds_permute never collides
@@ -396,7 +396,7 @@ __device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *_
 }
 
 // The same for a whole wave (every lane calls it; `alive` = this lane carries a ray): picks the
-// wave-cooperative scan when at most 16 lanes are live.  Returns the lane's new `alive`.
+// wave-cooperative scan when at most 32 lanes are live.  Returns the lane's new `alive`.
 template <bool DEFER_SKY>
 __device__ __forceinline__ bool path_step_wave(const DeviceScene &sc, const float4 *__restrict__ sph,
                                                const FrameParams &fp, Path &s, bool alive,
@@ -415,7 +415,7 @@ __device__ __forceinline__ bool path_step_wave(const DeviceScene &sc, const floa
       }
       alive = path_shade<DEFER_SKY>(sc, sph, fp, s, finish_hit(sc, sh, s.o, s.d), x1);
     }
-  } else if (n_live <= 16u) {
+  } else if (n_live <= 32u) {
     float x1 = 0.0f;
     if (alive) x1 = fp.rnd[rng_texel(fp, s.rng)];
     const SphereHit sh = scan_spheres_coop(sc, sph, s.o, s.d, alive, live, n_live);
