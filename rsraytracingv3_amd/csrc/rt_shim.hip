@@ -273,6 +273,8 @@ int rt_destroy(rt_context *ctx) {
 int rt_set_skybox(rt_context *ctx, uint32_t width, uint32_t height, const float *rgba32f) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!rgba32f || !width || !height) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_skybox: empty image");
+  if (width > 65536u || height > 65536u || static_cast<uint64_t>(width) * height > (1ull << 31))
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_skybox: %ux%u is beyond 65536 per side / 2^31 texels", width, height);
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const size_t bytes = static_cast<size_t>(width) * height * 16;
@@ -291,6 +293,7 @@ int rt_set_skybox(rt_context *ctx, uint32_t width, uint32_t height, const float 
 int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float *r32f) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!r32f || !width || !height) return RT_ERR_INVALID_ARGUMENT;  // no ctx->error write: other thread
+  if (width > 65536u || height > 65536u || static_cast<uint64_t>(width) * height > (1ull << 31)) return RT_ERR_INVALID_ARGUMENT;
   if (hipSetDevice(ctx->device) != hipSuccess) return RT_ERR_DEVICE;
   // Fill the copy no frame is reading, then publish it.  A frame launched meanwhile keeps
   // the old copy; one that used the target copy earlier is waited for on the upload stream.
@@ -329,6 +332,7 @@ int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float 
 int rt_generate_random(rt_context *ctx, uint32_t width, uint32_t height, uint64_t seed) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!width || !height) return RT_ERR_INVALID_ARGUMENT;
+  if (width > 65536u || height > 65536u || static_cast<uint64_t>(width) * height > (1ull << 31)) return RT_ERR_INVALID_ARGUMENT;
   if (hipSetDevice(ctx->device) != hipSuccess) return RT_ERR_DEVICE;
   // same double-buffer protocol as rt_set_random, filled by a kernel instead of a host copy
   int target;
@@ -474,6 +478,9 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
 int rt_resize(rt_context *ctx, uint32_t width, uint32_t height) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!width || !height) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_resize: zero size");
+  // pixel indices are 32-bit in the kernels (with room for the 8-row padding of a multi-frame launch)
+  if (width > 65536u || height > 65536u || static_cast<uint64_t>(width) * height > (1ull << 31))
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_resize: %ux%u is beyond 65536 per side / 2^31 pixels", width, height);
   RT_HIP(ctx, hipSetDevice(ctx->device));
   ctx->width = width;
   ctx->height = height;
@@ -560,6 +567,9 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   if (batch > 1u && (ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS)))
     return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_frames: the segments / hits outputs describe one frame; "
                                               "render batches with RT_OUT_RGBA8 | RT_OUT_RGBF32 only");
+  if (static_cast<uint64_t>((ctx->local_rows + 7u) / 8u * 8u) * ctx->width * batch > 0xffffffffull)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_frames: %u frames of %ux%u exceed 2^32 pixels per launch", batch,
+                ctx->width, ctx->local_rows);
   const float jitter_x = jitter[0], jitter_y = jitter[1];
   const uint32_t progressive_count = counts[0];
   if (!ctx->d_hdri) return fail(ctx, RT_ERR_NOT_READY, "rt_render: no skybox (rt_set_skybox)");

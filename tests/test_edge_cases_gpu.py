@@ -306,3 +306,12 @@ def test_skybox_from_an_exr_file(device, tmp_path):
         frames.append(target.read_rgbf32().copy())
     assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
     assert np.array_equal(frames[0].view(np.uint32), frames[2].view(np.uint32))
+
+
+def test_size_limits_are_refused_not_overflowed(device):
+    """Pixel indices are 32-bit on the device: sizes and launches beyond that are errors, never wrap-arounds."""
+    with pytest.raises(N.RtError, match="beyond 65536"):
+        device.call("rt_resize", 70000, 8)
+    with pytest.raises(N.RtError, match="beyond 65536"):
+        device.call("rt_resize", 65536, 65536)
+    device.call("rt_resize", 64, 64)  # the context stays usable
