@@ -246,7 +246,7 @@ int rt_create(int device_id, rt_context **out_ctx) {
 int rt_destroy(rt_context *ctx) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);  // also when the caller bound the null stream (rt_set_stream)
   if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
   free_target(ctx);
   (void)hipFree(ctx->d_hdri);

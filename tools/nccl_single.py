@@ -53,9 +53,26 @@ def main():
         if not np.array_equal(g, want[k]):
             bad += 1
             print("frame %d differs" % k)
+    # two launches of 8 progressive frames each through the same pipeline (one gather per launch)
+    jit2 = synth.jitter_sequence(9, 16)
+    launches = []
+    for b in range(2):
+        f = tiles.render(conn, jit2[8 * b:8 * b + 8], 8 * b)
+        if f is not None:
+            launches.append(f.cpu().numpy())
+    launches.append(tiles.finish().cpu().numpy())
+    dev.call("rt_bind_outputs", None, None, None)  # back to the context's own target for the reference run
+    for k in range(16):
+        conn.frame_data.jitter = (float(jit2[k, 0]), float(jit2[k, 1]))
+        conn.frame_data.progressive_count = k
+        conn.draw()
+        if k % 8 == 7:
+            if not np.array_equal(launches[k // 8].view(np.uint8).reshape(H, W, 4), target.read_rgba8()):
+                bad += 1
+                print("8-frame launch %d differs" % (k // 8))
     dev.close()
     dist.destroy_process_group()
-    print("nccl single-rank pipeline: %d frames, %d differing" % (6, bad))
+    print("nccl single-rank pipeline: %d frames + 2 launches of 8, %d differing" % (6, bad))
     return bad
 
 
