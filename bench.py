@@ -230,6 +230,7 @@ def main():
                                                                           ", RCCL gather to rank 0" if world > 1 else ""),
             "kernel_variant": args.variant,
             "frames_per_launch": B,
+            "progressive_count": "frame index k (1-spp frames of a resting camera accumulate, app.rs:208-254)",
             "one_frame_per_launch": single,
             "segments_per_pixel": round(total_seg / (float(W) * H * steps), 4),
             "mpixels_per_s": round(W * H * steps / elapsed / 1e6, 2),
