@@ -467,6 +467,8 @@ int rt_exr_read_rgba32f(const char *path, uint32_t *out_width, uint32_t *out_hei
   const int64_t W = static_cast<int64_t>(disp_win[2]) - disp_win[0] + 1, H = static_cast<int64_t>(disp_win[3]) - disp_win[1] + 1;
   if (dw <= 0 || dh <= 0 || W <= 0 || H <= 0 || dw > 65536 || dh > 65536 || W > 65536 || H > 65536)
     return exr_fail(bad + "unreasonable data / display window");
+  if (W * H > (1ll << 28) || dw * dh > (1ll << 28))  // 16k x 16k: 4 GiB of RGBA32F — far beyond any skybox
+    return exr_fail(bad + "image larger than 2^28 pixels");
   int idx[4] = {-1, -1, -1, -1};  // R G B A
   for (size_t i = 0; i < chans.size(); ++i) {
     if (chans[i].name == "R") idx[0] = static_cast<int>(i);
