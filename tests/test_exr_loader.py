@@ -2,6 +2,8 @@
 files written by tests/exr_writer.py: every supported compression, HALF / FLOAT / UINT channels, both PIZ
 wavelet modes, windows, line orders, raw-stored chunks, alpha handling and the reference's error texts.
 Host code only — runs without a GPU.  PARITY UNPINNED for files of other EXR writers (none exists here)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -130,3 +132,43 @@ def test_error_texts_follow_the_reference(tmp_path):
     with pytest.raises(N.RtError, match="Image invalid format"):
         Connection.load_image(path)
     assert truncated
+
+
+def test_corrupted_files_are_rejected_or_read_never_crash(tmp_path):
+    """Byte flips and truncations of valid files (every compression): the reader returns pixels or an error.
+    Runs in a child process so that a memory fault would fail this test instead of killing the test run."""
+    import subprocess
+    import sys
+    rgb = _image(40, 36, 4)
+    paths = []
+    for comp in (X.NONE, X.RLE, X.ZIPS, X.ZIP, X.PIZ):
+        p = str(tmp_path / ("h%d.exr" % comp))
+        X.write_exr(p, {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "half")}, comp)
+        paths.append(p)
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+from rsraytracingv3_amd import Connection
+from rsraytracingv3_amd import _native as N
+rs = np.random.RandomState(11)
+done = 0
+for path in %r:
+    good = bytearray(open(path, 'rb').read())
+    for trial in range(120):
+        data = bytearray(good)
+        if trial %% 3 == 0:
+            data = data[:rs.randint(1, len(data))]
+        else:
+            for _ in range(rs.randint(1, 6)):
+                data[rs.randint(0, len(data))] = rs.randint(0, 256)
+        open(path + '.bad', 'wb').write(bytes(data))
+        try:
+            Connection.load_image(path + '.bad')
+        except N.RtError:
+            pass
+        done += 1
+print('survived', done)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), paths)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "survived 600" in out.stdout
