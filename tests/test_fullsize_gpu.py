@@ -140,3 +140,18 @@ def test_rccl_pipeline_single_rank():
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "0 differing" in p.stdout
+
+
+def test_tile_parallel_two_ranks_sharing_this_gpu():
+    """tools/rehearse_tiles.py under torch.distributed.run with 2 ranks on this one GPU (gather staged through
+    gloo): single frames and 5-frame launches, strips gathered and de-interleaved on rank 0, bit-identical to
+    the oracle's frames.  The N > 1 composition short of RCCL itself (which needs one GPU per rank)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(root, "tools", "rehearse_tiles.py"), "--backend", "gloo"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "REHEARSAL OK" in p.stdout
