@@ -380,7 +380,10 @@ __device__ __forceinline__ bool path_shade(const DeviceScene &sc, const float4 *
   const float cosine = saturate(dot3(nrm, s.d));
   s.result = fma3(s.energy, mk3(m1.x, m1.y, m1.z), s.result);  // D1: energy before the update
   s.energy = s.energy * (mk3(m0.x, m0.y, m0.z) * cosine);      // frag.hlsl:27
-  if (length3(s.energy) < kEpsilon) return false;              // frag.hlsl:40-42
+  // frag.hlsl:40-42 `length(energy) < EPSILON`: the correctly rounded root is monotonic, so the test is a
+  // compare of the squared length with the smallest float whose root reaches EPSILON (0x2b8cbccb:
+  // sqrtf(it) >= 1e-6f, sqrtf(its predecessor) < 1e-6f; tests/test_oracle_math.py) — no root needed.
+  if (dot3(s.energy, s.energy) < __uint_as_float(0x2b8cbccbu)) return false;
   return s.seg < fp.reflection_limit;
 }
 

@@ -81,3 +81,17 @@ def test_asin_clamps_out_of_range_argument():
     x = np.array([1.0000001, -1.0000001, 3.0], np.float32)
     got = oracle.math_unary("asin", x)
     assert np.allclose(got, [np.pi / 2, -np.pi / 2, np.pi / 2], atol=2e-7)  # App. B D8
+
+
+def test_energy_cutoff_constant_is_the_exact_root_threshold():
+    """rt_kernels.hip replaces `length(energy) < EPSILON` (frag.hlsl:40-42) by `dot(energy, energy) < T`:
+    T must be the smallest float whose correctly rounded square root reaches EPSILON."""
+    import os
+    import re
+    eps = np.float32(0.000001)
+    t = np.uint32(0x2b8cbccb).view(np.float32)
+    below = np.nextafter(t, np.float32(0))
+    assert np.sqrt(t, dtype=np.float32) >= eps and np.sqrt(below, dtype=np.float32) < eps
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rsraytracingv3_amd", "csrc",
+                            "rt_kernels.hip")).read()
+    assert re.search(r"dot3\(s\.energy, s\.energy\) < __uint_as_float\(0x2b8cbccbu\)", src)
