@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT355_ABI_VERSION 1
+#define RT355_ABI_VERSION 2
 #define RT355_API __attribute__((visibility("default")))
 
 typedef enum rt_status {
@@ -70,6 +70,8 @@ typedef struct rt_stats {
                                     last_segments / (64 * this) = lane occupancy of the scan */
   uint64_t last_cull_mismatches; /* RT_OPT_CULL = 2: primary rays whose culled scan disagreed with the
                                     full scan in the last frame (must be 0)                    */
+  float last_resolve_ms;      /* HIP-event time of the last launch's history-resolve pass (n_frames > 1) */
+  uint32_t last_variant;      /* launch shape the last launch used (RT_OPT_VARIANT values 0..3)       */
 } rt_stats;
 
 /* Device-side view of the context's buffers, for zero-copy consumers (RCCL gather,
@@ -95,9 +97,6 @@ RT355_API uint32_t rt_abi_version(void);
  * (connection.rs:164-174). */
 RT355_API int rt_set_skybox(rt_context *ctx, uint32_t width, uint32_t height, const float *rgba32f);
 
-/* `RandomTexture::write` (src/gpu/random_texture.rs:78-101): R32F noise texture the
- * shader's random() indexes (src/shaders/random.hlsl:4-11).  Thread-safe against
- * every other call; a frame sees either the old or the new texture, never a mix. */
 /* `Connection::load_image` + `load_hdri` for the reference's asset format (connection.rs:154-215; `image`
  * 0.25.1 / `exr` 1.72.0 per Cargo.lock): read a single-part scan-line OpenEXR file (compression NONE,
  * RLE, ZIPS, ZIP or PIZ; HALF / FLOAT / UINT channels R, G, B and optionally A) into RGBA32F, alpha 1
@@ -110,6 +109,9 @@ RT355_API void rt_exr_free(float *rgba32f);
 RT355_API const char *rt_exr_last_error(void);
 RT355_API int rt_set_skybox_exr(rt_context *ctx, const char *path);
 
+/* `RandomTexture::write` (src/gpu/random_texture.rs:78-101): R32F noise texture the
+ * shader's random() indexes (src/shaders/random.hlsl:4-11).  Thread-safe against
+ * every other call; a frame sees either the old or the new texture, never a mix. */
 RT355_API int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float *r32f);
 
 /* Device-side replacement of the reference's generator thread (`RandomTexture::generate_data` +
@@ -173,6 +175,9 @@ RT355_API int rt_get_stats(rt_context *ctx, rt_stats *out);
  * n <= 512).  Any output pointer may be NULL.  Waits for the stream. */
 RT355_API int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segments, uint64_t *rough_hits,
                                    float *kernel_ms);
+/* HIP-event times of the history-resolve pass that follows the render kernel of a multi-frame launch
+ * (rt_render_frames), most recent n launches, oldest first; ~0 for single-frame launches. */
+RT355_API int rt_get_resolve_history(rt_context *ctx, uint32_t n, float *resolve_ms);
 /* Order all of the context's work on a caller-owned hipStream_t (e.g. the stream an RCCL
  * gather is issued on).  The default is a private non-blocking stream. */
 RT355_API int rt_set_stream(rt_context *ctx, void *hip_stream);

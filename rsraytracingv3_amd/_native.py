@@ -32,7 +32,8 @@ class RtStats(C.Structure):
                 ("last_pixels", C.c_uint64), ("last_kernel_ms", C.c_float), ("width", C.c_uint32),
                 ("height", C.c_uint32), ("local_rows", C.c_uint32), ("object_count", C.c_uint32),
                 ("sphere_count", C.c_uint32), ("plane_count", C.c_uint32), ("last_batch", C.c_uint32),
-                ("last_wave_iterations", C.c_uint64), ("last_cull_mismatches", C.c_uint64)]
+                ("last_wave_iterations", C.c_uint64), ("last_cull_mismatches", C.c_uint64),
+                ("last_resolve_ms", C.c_float), ("last_variant", C.c_uint32)]
 
 
 class RtDeviceBuffers(C.Structure):
@@ -74,6 +75,7 @@ SIGNATURES = {
     "rt_get_device_buffers": (_i, [_vp, C.POINTER(RtDeviceBuffers)]),
     "rt_get_stats": (_i, [_vp, C.POINTER(RtStats)]),
     "rt_get_frame_history": (_i, [_vp, _u32, _vp, _vp, _vp]),
+    "rt_get_resolve_history": (_i, [_vp, _u32, _vp]),
     "rt_set_stream": (_i, [_vp, _vp]),
     "rt_bind_outputs": (_i, [_vp, _vp, _vp, _vp]),
     "rt_last_error": (C.c_char_p, [_vp]),

@@ -33,6 +33,7 @@ import numpy as np
 from . import _native as N
 from . import synth
 from .bytes import bytes_concat, f32_bytes, u32_bytes
+from .rand_compat import fma_f32
 from .scene import Scene
 
 
@@ -299,8 +300,9 @@ class Connection:
             self.frame_data.progressive_count += 1
         if jitter is None:
             s = FrameData.JITTER_STRENGTH
-            jitter = (float(np.float32(self._jitter_rng.f32()) * np.float32(s) - np.float32(s / 2.0)),
-                      float(np.float32(self._jitter_rng.f32()) * np.float32(s) - np.float32(s / 2.0)))
+            half = -(np.float32(s) / np.float32(2.0))  # mul_add: one rounding (connection.rs:392-399)
+            jitter = (float(fma_f32(self._jitter_rng.f32(), np.float32(s), half)),
+                      float(fma_f32(self._jitter_rng.f32(), np.float32(s), half)))
         self.frame_data.jitter = (float(jitter[0]), float(jitter[1]))
 
     def draw(self):

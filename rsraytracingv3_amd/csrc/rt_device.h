@@ -108,7 +108,8 @@ struct LaunchConfig {
 int persistent_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);
 int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream);
-int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream);
+int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream,
+                  int *variant_used = nullptr);  // variant_used: the launch shape chosen (0..3)
 int launch_resolve(const ResolveParams &rp, hipStream_t stream);
 int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned long long *masks, hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);

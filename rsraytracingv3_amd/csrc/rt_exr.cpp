@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -58,6 +59,9 @@ struct Reader {
     return s;
   }
 };
+
+constexpr size_t kMaxChannels = 64;                 // more is a damaged or hostile header
+constexpr size_t kMaxBlockBytes = size_t{1} << 30;  // decoded bytes of one scan-line block
 
 struct Channel {
   std::string name;
@@ -386,9 +390,31 @@ const char *rt_exr_last_error(void) { return g_error.c_str(); }
 
 void rt_exr_free(float *rgba32f) { delete[] rgba32f; }
 
+// No C++ exception crosses the C boundary (rt355.h): allocation failures inside the reader become
+// RT_ERR_OUT_OF_MEMORY, anything else RT_ERR_INVALID_ARGUMENT.
+static int exr_read_impl(const char *path, uint32_t *out_width, uint32_t *out_height, float **out_rgba32f);
+
 int rt_exr_read_rgba32f(const char *path, uint32_t *out_width, uint32_t *out_height, float **out_rgba32f) {
   if (!path || !out_width || !out_height || !out_rgba32f) return exr_fail("rt_exr_read_rgba32f: NULL argument");
   *out_rgba32f = nullptr;
+  try {
+    return exr_read_impl(path, out_width, out_height, out_rgba32f);
+  } catch (const std::bad_alloc &) {
+    try {
+      g_error = "rt_exr_read_rgba32f: out of memory";
+    } catch (...) {
+    }
+    return RT_ERR_OUT_OF_MEMORY;
+  } catch (...) {
+    try {
+      g_error = "rt_exr_read_rgba32f: internal error while decoding";
+    } catch (...) {
+    }
+    return RT_ERR_INVALID_ARGUMENT;
+  }
+}
+
+static int exr_read_impl(const char *path, uint32_t *out_width, uint32_t *out_height, float **out_rgba32f) {
   FILE *f = std::fopen(path, "rb");
   if (!f) return exr_fail(std::string("Can't find image: ") + path);  // connection.rs:156
   std::vector<uint8_t> file;
@@ -437,6 +463,7 @@ int rt_exr_read_rgba32f(const char *path, uint32_t *out_width, uint32_t *out_hei
         if (!a.ok) return exr_fail(bad + "truncated channel list");
         if (c.type < 0 || c.type > 2) return exr_fail(bad + "unknown pixel type of channel " + c.name);
         if (xs != 1 || ys != 1) return exr_fail(bad + "subsampled channel " + c.name + " is not supported");
+        if (chans.size() >= kMaxChannels) return exr_fail(bad + "more than 64 channels");
         chans.push_back(c);
       }
     } else if (name == "compression" && type == "compression") {
@@ -483,12 +510,18 @@ int rt_exr_read_rgba32f(const char *path, uint32_t *out_width, uint32_t *out_hei
     chan_off.push_back(line_bytes);
     line_bytes += static_cast<size_t>(dw) * c.bytes();
   }
+  // A block's decoded bytes are held twice (raw + tmp): bound them before anything is allocated.  The
+  // largest sane block — 64 FLOAT channels would be absurd; 4 FLOAT channels x 65536 px x 32 lines is
+  // 32 MiB — is far below this cap.
+  if (line_bytes * static_cast<size_t>(lines_per_block) > kMaxBlockBytes)
+    return exr_fail(bad + "scan-line block larger than 1 GiB");
   const size_t n_blocks = static_cast<size_t>((dh + lines_per_block - 1) / lines_per_block);
   if (static_cast<size_t>(r.end - r.p) < n_blocks * 8) return exr_fail(bad + "truncated offset table");
   std::vector<uint64_t> offsets(n_blocks);
   std::memcpy(offsets.data(), r.p, n_blocks * 8);
 
-  float *rgba = new (std::nothrow) float[static_cast<size_t>(W) * H * 4];
+  std::unique_ptr<float[]> owner(new (std::nothrow) float[static_cast<size_t>(W) * H * 4]);
+  float *rgba = owner.get();
   if (!rgba) {
     g_error = "rt_exr_read_rgba32f: out of memory";
     return RT_ERR_OUT_OF_MEMORY;
@@ -497,10 +530,7 @@ int rt_exr_read_rgba32f(const char *path, uint32_t *out_width, uint32_t *out_hei
   std::memset(rgba, 0, static_cast<size_t>(W) * H * 16);
   std::vector<uint8_t> raw, tmp;
   for (size_t b = 0; b < n_blocks; ++b) {
-    auto fail_block = [&](const char *why) {
-      delete[] rgba;
-      return exr_fail(bad + why);
-    };
+    auto fail_block = [&](const char *why) { return exr_fail(bad + why); };
     if (offsets[b] > file.size() || file.size() - offsets[b] < 8) return fail_block("chunk offset outside the file");
     Reader c{file.data() + offsets[b], file.data() + file.size()};
     const int32_t y0 = c.get<int32_t>();
@@ -565,7 +595,7 @@ int rt_exr_read_rgba32f(const char *path, uint32_t *out_width, uint32_t *out_hei
   }
   *out_width = static_cast<uint32_t>(W);
   *out_height = static_cast<uint32_t>(H);
-  *out_rgba32f = rgba;
+  *out_rgba32f = owner.release();
   return RT_OK;
 }
 
@@ -573,7 +603,7 @@ int rt_set_skybox_exr(rt_context *ctx, const char *path) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   uint32_t w = 0, h = 0;
   float *rgba = nullptr;
-  const int rc = rt_exr_read_rgba32f(path, &w, &h, &rgba);
+  const int rc = rt_exr_read_rgba32f(path, &w, &h, &rgba);  // catches every exception itself
   if (rc != RT_OK) return rc;
   const int rc2 = rt_set_skybox(ctx, w, h, rgba);
   rt_exr_free(rgba);

@@ -552,7 +552,12 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
 template <int NW>
 __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_all[];
-  __shared__ unsigned int wave_count[NW];
+  // Live-path counts of the waves, double-buffered by iteration parity: iteration k writes and reads
+  // wave_count[k & 1].  A wave reaches its write of iteration k+2 (same buffer) only after the count
+  // barrier of iteration k+1, which every live wave joins after it has finished its iteration-k reads
+  // (program order), so no write can pass a read of the value it replaces — also on iterations that
+  // do not pack and therefore have no second barrier.
+  __shared__ unsigned int wave_count[2][NW];
   float4 *lds_sph = lds_all;
   float4 *xchg = lds_all + sc.n_sph_pad;  // kXchgPaths paths x 4 float4
   for (uint32_t i = threadIdx.x; i < sc.n_sph_pad; i += NW * 64) lds_sph[i] = sc.sph[i];
@@ -595,14 +600,15 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
       s.rough = 0;
       finished |= was & !alive;
     }
+    unsigned int *counts = wave_count[iters & 1u];
     iters += 1u;
     const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
-    if (lane == 0) wave_count[wave] = static_cast<uint32_t>(__popcll(live));
+    if (lane == 0) counts[wave] = static_cast<uint32_t>(__popcll(live));
     __syncthreads();
     uint32_t total = 0, before = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const uint32_t c = (static_cast<uint32_t>(w) < live_waves) ? wave_count[w] : 0u;
+      const uint32_t c = (static_cast<uint32_t>(w) < live_waves) ? counts[w] : 0u;
       before += (static_cast<uint32_t>(w) < wave) ? c : 0u;
       total += c;
     }
@@ -929,7 +935,7 @@ __global__ void sqrt_exhaustive_kernel(unsigned long long *mismatches) {
 
 }  // namespace
 
-int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream) {
+int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream, int *variant_used) {
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
   const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
   if (fp.batch < 1u || fp.batch > kMaxBatch || fp.frame_tile_rows != tiles_y) return static_cast<int>(hipErrorInvalidValue);
@@ -950,6 +956,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   if (variant == 3 && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26))) variant = 0;
   // scenes whose sphere records do not fit a workgroup's default 64 KB of LDS are scanned from global memory
   if (lds + (variant == 3 ? kXchgPaths * 64u : 0u) > 60u * 1024u) variant = 1;
+  if (variant_used) *variant_used = variant;
   if (variant == 2) {
     uint32_t blocks = static_cast<uint32_t>(lc.persistent_blocks);
     const uint64_t max_useful = (tiles + (kBlock / 64) - 1) / (kBlock / 64);

@@ -31,7 +31,7 @@ struct rt_context {
   static constexpr uint32_t kRing = 1024;
   static constexpr uint32_t kCounterWords = kTotalShards * kTotalShardStride;  // u64 words per ring slot
   static constexpr uint32_t kTileWords = 8 * 32; // u32 words per ring slot: 8 shard counters, 128 B apart
-  std::vector<hipEvent_t> ev_start, ev_stop;
+  std::vector<hipEvent_t> ev_start, ev_stop, ev_resolved;  // render kernel = start..stop, resolve pass = stop..resolved
   bool timing_valid = false;
 
   // skybox
@@ -65,6 +65,8 @@ struct rt_context {
   uint32_t *d_segments = nullptr;
   int32_t *d_hits = nullptr;
   uint32_t hits_limit = 0;  // reflection_limit the hits buffer was sized for
+  uint32_t hits_rendered_limit = 0;  // reflection_limit of the frame the hits buffer holds
+  bool hits_valid = false;           // a frame has been rendered into the hits buffer since it was allocated
   unsigned long long *d_counters = nullptr;  // kRing x kTotalShards x 128 B lines of {segments, rough hits, wave iterations}
   unsigned int *d_tile_counters = nullptr;   // kRing x kTileWords (variant 2 work counters)
   // caller-owned output buffers (rt_bind_outputs); null = the context's own
@@ -129,16 +131,11 @@ void free_target(rt_context *ctx) {
   ctx->d_segments = nullptr;
   ctx->d_hits = nullptr;
   ctx->hits_limit = 0;
+  ctx->hits_valid = false;
 }
 
 // (re)allocate per-pixel buffers for the current size / partition / outputs / accum mode
-int alloc_target(rt_context *ctx) {
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  free_target(ctx);
-  ctx->local_rows = count_local_rows(ctx->height, ctx->rank, ctx->world, ctx->strip_rows);
-  ctx->masks_dirty = true;
-  const size_t px = static_cast<size_t>(ctx->local_rows) * ctx->width;
-  if (px == 0) return RT_OK;
+int alloc_target_buffers(rt_context *ctx, size_t px) {
   RT_HIP(ctx, hipMalloc(&ctx->d_rgba8, px * 4));
   RT_HIP(ctx, hipMemsetAsync(ctx->d_rgba8, 0, px * 4, ctx->stream));
   if (ctx->out_flags & RT_OUT_RGBF32) RT_HIP(ctx, hipMalloc(&ctx->d_rgbf32, px * 12));
@@ -150,12 +147,28 @@ int alloc_target(rt_context *ctx) {
   return RT_OK;
 }
 
+int alloc_target(rt_context *ctx) {
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_target(ctx);
+  ctx->local_rows = count_local_rows(ctx->height, ctx->rank, ctx->world, ctx->strip_rows);
+  ctx->masks_dirty = true;
+  const size_t px = static_cast<size_t>(ctx->local_rows) * ctx->width;
+  if (px == 0) return RT_OK;
+  const int rc = alloc_target_buffers(ctx, px);
+  if (rc != RT_OK) {  // never leave a size behind that has no buffers: the context is back to "no target"
+    free_target(ctx);
+    ctx->width = ctx->height = ctx->local_rows = 0;
+  }
+  return rc;
+}
+
 int ensure_hits(rt_context *ctx, uint32_t limit) {
   if (!(ctx->out_flags & RT_OUT_HITS)) return RT_OK;
   if (ctx->d_hits && ctx->hits_limit >= limit) return RT_OK;
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   (void)hipFree(ctx->d_hits);
   ctx->d_hits = nullptr;
+  ctx->hits_valid = false;
   const size_t n = static_cast<size_t>(ctx->local_rows) * ctx->width * (limit ? limit : 1);
   if (n) RT_HIP(ctx, hipMalloc(&ctx->d_hits, n * 4));
   ctx->hits_limit = limit;
@@ -222,8 +235,10 @@ int rt_create(int device_id, rt_context **out_ctx) {
   if (hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking) != hipSuccess) return bail(RT_ERR_DEVICE);
   ctx->ev_start.assign(rt_context::kRing, nullptr);
   ctx->ev_stop.assign(rt_context::kRing, nullptr);
+  ctx->ev_resolved.assign(rt_context::kRing, nullptr);
   for (uint32_t i = 0; i < rt_context::kRing; ++i)
-    if (hipEventCreate(&ctx->ev_start[i]) != hipSuccess || hipEventCreate(&ctx->ev_stop[i]) != hipSuccess)
+    if (hipEventCreate(&ctx->ev_start[i]) != hipSuccess || hipEventCreate(&ctx->ev_stop[i]) != hipSuccess ||
+        hipEventCreate(&ctx->ev_resolved[i]) != hipSuccess)
       return bail(RT_ERR_DEVICE);
   for (int i = 0; i < 2; ++i)
     if (hipEventCreateWithFlags(&ctx->rnd_last_use[i], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
@@ -263,6 +278,8 @@ int rt_destroy(rt_context *ctx) {
   for (hipEvent_t e : ctx->ev_start)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_stop)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_resolved)
     if (e) (void)hipEventDestroy(e);
   if (ctx->stream && ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
@@ -714,13 +731,20 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   lc.persistent_blocks = per_cu * ctx->cu_count;
   lc.tile_chunk = ctx->tile_chunk;
   lc.flags = ctx->flags;
-  const int lrc = launch_render(ctx->scene, fp, lc, ctx->stream);
+  int variant_used = -1;
+  const int lrc = launch_render(ctx->scene, fp, lc, ctx->stream, &variant_used);
   if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
   RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], ctx->stream));
   RT_HIP(ctx, hipEventRecord(ctx->rnd_last_use[rnd], ctx->stream));
   ctx->rnd_used[rnd] = true;
   rnd_lock.unlock();
   if (batch > 1u && launch_resolve(rp, ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "resolve launch failed");
+  RT_HIP(ctx, hipEventRecord(ctx->ev_resolved[slot], ctx->stream));
+  ctx->stats.last_variant = static_cast<uint32_t>(variant_used);
+  if (fp.hits) {
+    ctx->hits_valid = true;
+    ctx->hits_rendered_limit = fp.reflection_limit;
+  }
   ctx->timing_valid = true;
   ctx->stats.frames += 1;
   ctx->stats.last_batch = batch;
@@ -775,7 +799,14 @@ int rt_read_segments(rt_context *ctx, uint32_t *dst, size_t bytes) {
 }
 int rt_read_hits(rt_context *ctx, int32_t *dst, size_t bytes) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
-  return read_back(ctx, ctx->d_hits, dst, bytes, 4 * static_cast<size_t>(ctx->config.reflection_limit), "rt_read_hits");
+  // The buffer holds the last RENDERED frame: its stride is that frame's reflection_limit, which a later
+  // rt_set_scene may have changed (and the allocation only grows at the next render).
+  if (ctx->d_hits && !ctx->hits_valid)
+    return fail(ctx, RT_ERR_NOT_READY, "rt_read_hits: no frame rendered since the target was (re)allocated");
+  if (ctx->d_hits && ctx->hits_rendered_limit != ctx->config.reflection_limit)
+    return fail(ctx, RT_ERR_NOT_READY, "rt_read_hits: the last frame was rendered with reflection_limit %u, the scene now "
+                                       "has %u; render a frame first", ctx->hits_rendered_limit, ctx->config.reflection_limit);
+  return read_back(ctx, ctx->d_hits, dst, bytes, 4 * static_cast<size_t>(ctx->hits_rendered_limit), "rt_read_hits");
 }
 
 int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes) {
@@ -822,6 +853,8 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     float ms = 0.0f;
     RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
     ctx->stats.last_kernel_ms = ms;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_stop[slot], ctx->ev_resolved[slot]));
+    ctx->stats.last_resolve_ms = ms;
   }
   ctx->stats.last_pixels = static_cast<uint64_t>(ctx->local_rows) * ctx->width * (ctx->stats.last_batch ? ctx->stats.last_batch : 1u);
   ctx->stats.width = ctx->width;
@@ -854,6 +887,20 @@ int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segments, uint64
   return RT_OK;
 }
 
+int rt_get_resolve_history(rt_context *ctx, uint32_t n, float *resolve_ms) {
+  if (!ctx || !resolve_ms) return RT_ERR_INVALID_ARGUMENT;
+  if (n > rt_context::kRing / 2 || n > ctx->stats.frames)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_get_resolve_history: %u launches asked, %llu made, ring keeps %u", n,
+                static_cast<unsigned long long>(ctx->stats.frames), rt_context::kRing / 2);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t k = 0; k < n; ++k) {  // oldest first
+    const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - n + k) % rt_context::kRing);
+    RT_HIP(ctx, hipEventElapsedTime(&resolve_ms[k], ctx->ev_stop[slot], ctx->ev_resolved[slot]));
+  }
+  return RT_OK;
+}
+
 int rt_set_stream(rt_context *ctx, void *hip_stream) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -878,11 +925,14 @@ int rt_selftest_math_unary(rt_context *ctx, int op, const float *x, float *y, si
   if (!ctx || !x || !y) return RT_ERR_INVALID_ARGUMENT;
   RT_HIP(ctx, hipSetDevice(ctx->device));
   float *dx = nullptr, *dy = nullptr;
-  RT_HIP(ctx, hipMalloc(&dx, n * 4 + 4));
-  RT_HIP(ctx, hipMalloc(&dy, n * 4 + 4));
-  RT_HIP(ctx, hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice));
-  const int rc = launch_math_unary(op, dx, dy, n, ctx->stream);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipMalloc(&dx, n * 4 + 4);
+  if (e == hipSuccess) e = hipMalloc(&dy, n * 4 + 4);
+  if (e == hipSuccess) e = hipMemcpy(dx, x, n * 4, hipMemcpyHostToDevice);
+  int rc = 0;
+  if (e == hipSuccess) {
+    rc = launch_math_unary(op, dx, dy, n, ctx->stream);
+    e = hipStreamSynchronize(ctx->stream);
+  }
   if (rc == 0 && e == hipSuccess) e = hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost);
   (void)hipFree(dx);
   (void)hipFree(dy);
@@ -894,13 +944,16 @@ int rt_selftest_math_binary(rt_context *ctx, int op, const float *a, const float
   if (!ctx || !a || !b || !y) return RT_ERR_INVALID_ARGUMENT;
   RT_HIP(ctx, hipSetDevice(ctx->device));
   float *da = nullptr, *db = nullptr, *dy = nullptr;
-  RT_HIP(ctx, hipMalloc(&da, n * 4 + 4));
-  RT_HIP(ctx, hipMalloc(&db, n * 4 + 4));
-  RT_HIP(ctx, hipMalloc(&dy, n * 4 + 4));
-  RT_HIP(ctx, hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
-  RT_HIP(ctx, hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
-  const int rc = launch_math_binary(op, da, db, dy, n, ctx->stream);
-  hipError_t e = hipStreamSynchronize(ctx->stream);
+  hipError_t e = hipMalloc(&da, n * 4 + 4);
+  if (e == hipSuccess) e = hipMalloc(&db, n * 4 + 4);
+  if (e == hipSuccess) e = hipMalloc(&dy, n * 4 + 4);
+  if (e == hipSuccess) e = hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice);
+  int rc = 0;
+  if (e == hipSuccess) {
+    rc = launch_math_binary(op, da, db, dy, n, ctx->stream);
+    e = hipStreamSynchronize(ctx->stream);
+  }
   if (rc == 0 && e == hipSuccess) e = hipMemcpy(y, dy, n * 4, hipMemcpyDeviceToHost);
   (void)hipFree(da);
   (void)hipFree(db);

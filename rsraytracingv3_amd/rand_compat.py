@@ -21,6 +21,29 @@ _M32 = 0xFFFFFFFF
 _M64 = 0xFFFFFFFFFFFFFFFF
 
 
+def fma_f32(a, b, c) -> np.float32:
+    """``f32::mul_add`` (scene.rs:105-107, connection.rs:392-399): a*b + c rounded ONCE to binary32,
+    nearest-even.  Evaluated exactly in rational arithmetic, so neither the product nor a float64
+    intermediate rounds first (float64 would round twice).  Normal-range results only."""
+    from fractions import Fraction
+    x = Fraction(float(np.float32(a))) * Fraction(float(np.float32(b))) + Fraction(float(np.float32(c)))
+    if x == 0:
+        return np.float32(0.0)
+    n = abs(x)
+    e = n.numerator.bit_length() - n.denominator.bit_length()  # 2^(e-1) < n < 2^(e+1)
+    if Fraction(2) ** e > n:
+        e -= 1                                                  # now 2^e <= n < 2^(e+1)
+    q = n / Fraction(2) ** (e - 23)                             # in [2^23, 2^24)
+    m = q.numerator // q.denominator
+    rem = q - m
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (m & 1)):
+        m += 1
+    v = float(m) * 2.0 ** (e - 23)                              # exact: m <= 2^24
+    out = np.float32(-v if x < 0 else v)
+    assert -126 <= e <= 127 and float(out) == (-v if x < 0 else v)
+    return out
+
+
 def _rotl32(x: int, n: int) -> int:
     return ((x << n) | (x >> (32 - n))) & _M32
 

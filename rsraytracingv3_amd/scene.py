@@ -2,11 +2,12 @@
 ``src/ray_tracer/{objects,scene,camera}.rs``.
 
 Only what feeds the hot path is mirrored: the byte layouts (``as_bytes``), the
-size constants, the camera basis and a synthetic scene generator that draws from
-the same distributions as ``Scene::random_spheres`` (scene.rs:95-231).  The
-reference's generator runs on ``rand``'s ChaCha12 ``StdRng``; this one runs on a
-documented SplitMix64 stream (``synth.SplitMix64``), so scenes are reproducible
-here but not bit-identical to the reference's seed-42 scene.
+size constants, the camera basis and two scene generators with the distributions of
+``Scene::random_spheres`` (scene.rs:95-231): ``Scene.random_spheres`` on a documented
+SplitMix64 stream (``synth.SplitMix64``; the benchmark scenes), and
+``Scene.random_spheres_reference`` on the reference's own stream (``rand``'s ChaCha12
+``StdRng``, ``rand_compat``), which regenerates the reference's seed-42 start-up scene
+bit for bit (pinned by the values its screenshot shows).
 """
 from __future__ import annotations
 
@@ -258,14 +259,14 @@ class Scene:
         """scene.rs:152-231 on the reference's own random stream (``StdRng::seed_from_u64`` = ChaCha12,
         ``rand_compat.StdRng``): reproduces the reference's default scene bit for bit — Sphere 0 matches
         the values its screenshot shows.  float32 arithmetic follows the Rust expressions."""
-        from .rand_compat import StdRng
+        from .rand_compat import StdRng, fma_f32
         f = np.float32
         rng = StdRng.seed_from_u64(seed)
         objects: List[Object] = []
         for i in range(sphere_count):
             placed = None
             for _ in range(100):                                   # scene.rs:104
-                radius = f(rng.gen_f32() * f(max_radius - min_radius) + f(min_radius))   # mul_add (scene.rs:105-107)
+                radius = fma_f32(rng.gen_f32(), f(max_radius) - f(min_radius), f(min_radius))  # mul_add: ONE rounding (scene.rs:105-107)
                 x, y = rng.unit_disc()                             # scene.rs:108
                 cx, cz = f(x * f(placement_radius)), f(y * f(placement_radius))
                 ok = True

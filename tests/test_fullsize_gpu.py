@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 SKY = None
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def sky():
     global SKY
     if SKY is None:
@@ -135,7 +144,7 @@ def test_rccl_pipeline_single_rank():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "nccl_single.py")], env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -151,7 +160,7 @@ def test_tile_parallel_two_ranks_sharing_this_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29537", os.path.join(root, "tools", "rehearse_tiles.py"), "--backend", "gloo"]
+           "--master-port", str(_free_port()), os.path.join(root, "tools", "rehearse_tiles.py"), "--backend", "gloo"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "REHEARSAL OK" in p.stdout
