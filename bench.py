@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
 """rt355 benchmark — BASELINE.json metric: Mrays/s at 1920x1080, 64 spheres, 8 bounces.
 
-A step is one frame (1 spp, progressive_count 0) of BASELINE config 2 through the C-ABI:
-64 spheres + the ground plane (65 live objects), 2048x1024 RGBA32F skybox, 600x600 random
-texture, all resident in HBM before the timed region.  A ray = one executed iteration of
-the bounce loop (frag.hlsl:36-43).  N GPUs split the same frame into row strips
-(strong scaling) and gather the sRGB8 texels on rank 0 over RCCL.
+A step is one 1-spp frame of BASELINE config 2 through the C-ABI: 64 spheres + the ground plane (65 live
+objects), 2048x1024 RGBA32F skybox, 600x600 random texture, everything resident in HBM before the timed
+region.  The frames are the progressive accumulation of a resting camera (frame k has progressive_count k,
+app.rs:208-254 / connection.rs:386-388).  A ray = one executed iteration of the bounce loop
+(frag.hlsl:36-43).  N GPUs split every frame into row strips and gather the sRGB8 texels on rank 0.
 
-Prints ONE JSON line on rank 0.  `roofline` prices the render kernel's ALGORITHMIC bytes
-(8 B/pixel + 16 B/segment + 8 B/rough hit) against the 8 TB/s HBM peak, from
-per-launch HIP-event durations taken inside the timed region; `valu` prices the algorithmic
-flops against the 157.3 TFLOP/s FP32 vector peak (the bound that actually binds — DESIGN.md).
-`cpu_baseline` is the CPU oracle (OpenMP) on the same frame, reported, not targeted.
+Protocol: an untimed clock warm-up of >= 2 s of back-to-back launches (on top of the
+--warmup steps), then the block of EXACTLY --steps steps — bracketed by barrier + synchronize on both sides,
+MAX over ranks — is repeated until >= 1 s has been measured and the MEDIAN block is reported
+(`steps`, `ms_per_step` keep their meaning: ms_per_step = median block / steps).
+
+`value` is the headline leg: 8 frames per launch per GPU (rt_render_frames).  The same JSON line always
+carries, under `config`, the one-frame-per-launch leg (the reference's call pattern: one draw per loop turn)
+and the reference-exact 80-slot leg (15 zero-padded objects scanned as the reference's shader does).
+
+`roofline` prices the render kernel's ALGORITHMIC bytes (8 B/pixel + 16 B/segment +
+8 B/rough hit) against the 8 TB/s HBM peak, from per-launch HIP-event durations taken on the context's stream
+inside the timed region; `valu` prices the algorithmic flops against the 157.3 TFLOP/s FP32 vector peak (the
+bound that binds — DESIGN.md §5).  `cpu_baseline` is the CPU oracle (OpenMP) on the same frames, reported,
+not targeted.
 """
 import argparse
 import ctypes as C
@@ -28,6 +37,10 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 VALU_PEAK_TFLOPS = 157.3    # FP32 vector peak
+SIMDS = 1024                # 256 CUs x 4
+CLOCK_WARMUP_S = 2.0
+MIN_TIMED_S = 1.0
+KERNEL_NAMES = {0: "render_tiles<true>", 1: "render_tiles<false>", 2: "render_persistent", 3: "render_blocks<4>"}
 
 
 def algorithmic_bytes(pixels, segments, rough):
@@ -57,11 +70,12 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive 1-spp frames per kernel launch (rt_render_frames, 1..64); 0 = 8 per GPU of the job, "
                          "so that a launch carries eight frames' worth of tiles whatever the partition")
-    ap.add_argument("--single-frame-reference", action="store_true",
-                    help="also time 100 frames submitted one per launch (reported in config.one_frame_per_launch)")
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo = 1-GPU rehearsal via host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the one-frame-per-launch and 80-slot legs (profiling)")
+    ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_S, help="minimum timed window of a leg")
+    ap.add_argument("--clock-warmup", type=float, default=CLOCK_WARMUP_S, help="seconds of untimed launches before timing")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
     args = ap.parse_args()
 
@@ -76,8 +90,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
-    if args.steps > 512:
-        raise SystemExit("bench.py: --steps must be <= 512 (per-frame event ring)")
+    if args.steps < 1 or args.steps > 512:
+        raise SystemExit("bench.py: --steps must be 1..512 (per-launch event ring)")
     if not 0 <= args.batch <= 64:
         raise SystemExit("bench.py: --batch must be 0 (auto) or 1..64")
     local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal: several ranks on one GPU
@@ -92,10 +106,10 @@ def main():
     W, H = args.width, args.height
     scene = cases.spheres_scene(args.spheres, args.bounces, seed=42, request=max(100, int(args.spheres * 1.6))) \
         if args.spheres <= 64 else cases.stress_scene(args.spheres, args.bounces)
-    n_objects = len(scene.objects) if args.slots == 0 else args.slots
     sky = synth.procedural_skybox(args.sky, args.sky // 2)
     rnd = synth.random_texture(1)
-    jit = synth.jitter_sequence(42, args.steps + args.warmup + 64)
+    n_jit = 4096
+    jit = synth.jitter_sequence(42, n_jit)
 
     dev = Device(local_rank)
     dev.set_outputs(N.RT_OUT_RGBA8)
@@ -103,7 +117,7 @@ def main():
     dev.set_option(N.RT_OPT_REFILL_MIN, args.refill_min)
     dev.set_option(N.RT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
     dev.set_option(N.RT_OPT_TILE_CHUNK, args.tile_chunk)
-    dev.set_option(4, args.flags)
+    dev.set_option(N.RT_OPT_FLAGS, args.flags)
     target = RenderTarget.new(dev, (W, H))
     rt = RandomTexture(dev)
     rt.write(rnd)
@@ -115,23 +129,20 @@ def main():
         from rsraytracingv3_amd.distributed import TileParallelRenderer
         tiles = TileParallelRenderer(dev, W, H, args.strip_rows)
 
-    # A step is one 1-spp frame of the progressive accumulation (frame k has progressive_count k, as in the
-    # reference's loop while the camera rests); --batch B > 1 submits B consecutive frames per launch.
-    B = args.batch if args.batch > 0 else min(64, 8 * world)
-
-    def run_frames(first, count):
-        """frames first .. first+count-1; returns the number of launches"""
+    def run_frames(first, count, B):
+        """frames first .. first+count-1 of the accumulation, B per launch; returns the number of launches"""
         k, launches = first, 0
         while k < first + count:
             n = min(B, first + count - k)
+            j = jit[np.arange(k, k + n) % n_jit]
             if tiles is not None:  # rank 0 gets the previous launch's image assembled while this one renders
-                tiles.render(conn, jit[k] if B == 1 else jit[k:k + n], k)
+                tiles.render(conn, j[0] if B == 1 else j, k)
             elif B == 1:
-                conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
+                conn.frame_data.jitter = (float(j[0, 0]), float(j[0, 1]))
                 conn.frame_data.progressive_count = k
                 conn.draw()
             else:
-                conn.draw_frames(jit[k:k + n], k)
+                conn.draw_frames(j, k)
             k += n
             launches += 1
         return launches
@@ -145,71 +156,132 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warm-up in whole launches (W rounded up to a multiple of the batch), so that every launch a profiler
-    # sees carries the same number of frames as the timed ones
-    warm_frames = -(-args.warmup // B) * B
-    run_frames(0, warm_frames)
-    fence()
-    t0 = time.perf_counter()
-    launches = run_frames(warm_frames, args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def agree(flag):
+        """Loop-exit decisions must be the same on every rank (each rank has its own clock)."""
+        if world == 1:
+            return flag
+        t = torch.tensor([1.0 if flag else 0.0], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0.5)
 
-    # per-launch totals and HIP-event kernel durations of the timed region
-    seg = np.zeros(launches, np.uint64)
-    rough = np.zeros(launches, np.uint64)
-    kms = np.zeros(launches, np.float32)
-    dev.call("rt_get_frame_history", launches, seg.ctypes.data_as(C.c_void_p), rough.ctypes.data_as(C.c_void_p),
-             kms.ctypes.data_as(C.c_void_p))
-    st = dev.stats()
-    frame_px = float(st.last_pixels) / max(int(st.last_batch), 1)  # this rank's pixels of one frame
-    local = torch.tensor([elapsed, float(seg.sum()), float(rough.sum()), float(kms.sum()), frame_px],
-                         dtype=torch.float64, device="cuda")
-    if world > 1:
-        mx = local.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = local.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-        total_seg, total_rough, total_px = float(sm[1]), float(sm[2]), float(sm[4])
-    else:
-        total_seg, total_rough, total_px = float(local[1]), float(local[2]), float(local[4])
+    def timed_leg(B, steps, warm_steps, min_seconds, clock_warmup):
+        """Clock warm-up, `warm_steps` untimed steps, then blocks of exactly `steps` steps until min_seconds
+        have been measured.  Returns the per-block records; the caller reports the median block."""
+        first = 0
+        t_end = time.perf_counter() + clock_warmup
+        while True:  # untimed: back-to-back launches so the clock has settled (DVFS) before anything is timed
+            run_frames(first, 8 * B, B)
+            first += 8 * B
+            dev.sync()
+            if not agree(time.perf_counter() < t_end):
+                break
+        warm = -(-warm_steps // B) * B  # whole launches, so every launch a profiler sees has the timed shape
+        if warm:
+            run_frames(first, warm, B)
+            first += warm
+        fence()
+        blocks, measured = [], 0.0
+        while True:
+            t0 = time.perf_counter()
+            launches = run_frames(first, steps, B)
+            fence()
+            dt = time.perf_counter() - t0
+            seg = np.zeros(launches, np.uint64)
+            rough = np.zeros(launches, np.uint64)
+            kms = np.zeros(launches, np.float32)
+            rms = np.zeros(launches, np.float32)
+            dev.call("rt_get_frame_history", launches, seg.ctypes.data_as(C.c_void_p), rough.ctypes.data_as(C.c_void_p),
+                     kms.ctypes.data_as(C.c_void_p))
+            dev.call("rt_get_resolve_history", launches, rms.ctypes.data_as(C.c_void_p))
+            blocks.append({"dt": dt, "launches": launches, "seg": float(seg.sum()), "rough": float(rough.sum()),
+                           "kernel_ms": float(kms.sum()), "resolve_ms": float(rms.sum()), "first": first,
+                           "seg_first_launch": int(seg[0])})
+            measured += dt
+            if not agree(measured < min_seconds and len(blocks) < 4096):
+                break
+        return blocks
+
+    def reduce_leg(blocks):
+        """Median block (by the MAX-over-ranks time) and whole-job totals of that block."""
+        st = dev.stats()
+        frame_px = float(st.last_pixels) / max(int(st.last_batch), 1)  # this rank's pixels of one frame
+        dts = torch.tensor([b["dt"] for b in blocks], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+        order = torch.argsort(dts)
+        mid = int(order[(len(blocks) - 1) // 2])
+        b = blocks[mid]
+        tot = torch.tensor([b["seg"], b["rough"], frame_px], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        return {"elapsed": float(dts[mid]), "block": b, "n_blocks": len(blocks), "total_seg": float(tot[0]),
+                "total_rough": float(tot[1]), "total_px": float(tot[2]), "frame_px": frame_px, "stats": st,
+                "dt_min": float(dts.min()), "dt_max": float(dts.max()), "measured_s": float(dts.sum())}
+
+    # ---- headline leg: B frames per launch ------------------------------------------------------------------
+    B = args.batch if args.batch > 0 else min(64, 8 * world)
+    head = reduce_leg(timed_leg(B, args.steps, args.warmup, args.min_seconds, args.clock_warmup))
+    variant_used = int(head["stats"].last_variant)
+
+    # ---- extra legs: one frame per launch (reference call pattern); 80 zero-padded slots ------------------
+    def leg_summary(leg, frames_per_launch):
+        blk = leg["block"]
+        return {"frames_per_launch": frames_per_launch, "steps": args.steps,
+                "ms_per_step": round(leg["elapsed"] / args.steps * 1e3, 5),
+                "mrays_per_s": round(leg["total_seg"] / leg["elapsed"] / 1e6, 2),
+                "kernel_mrays_per_s": round(blk["seg"] / (blk["kernel_ms"] * 1e-3) / 1e6, 2) if blk["kernel_ms"] else None,
+                "kernel": KERNEL_NAMES.get(int(leg["stats"].last_variant), "?"), "blocks_timed": leg["n_blocks"]}
+
+    single = slots80 = None
+    if not args.no_extra_legs:
+        if B > 1:
+            single = leg_summary(reduce_leg(timed_leg(1, args.steps, 8, args.min_seconds / 2, 0.25)), 1)
+        if world == 1 and args.slots == 0 and len(scene.objects) <= 80:
+            conn.max_objects = 80      # connection.rs: the fixed 80-slot buffer, zero-filled tail (scene.rs:28)
+            conn.last_size = (0, 0)    # force the dirty branch of update_buffers
+            conn.update_buffers((W, H), scene, (0.0, 0.0))
+            leg80 = reduce_leg(timed_leg(B, args.steps, 8, args.min_seconds / 2, 0.25))
+            slots80 = leg_summary(leg80, B)
+            f80 = algorithmic_flops(leg80["frame_px"] * args.steps, leg80["block"]["seg"], 80)
+            slots80["valu_frac"] = round(f80 / (leg80["block"]["kernel_ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 5)
+            conn.max_objects = "live"
+            conn.last_size = (0, 0)
+            conn.update_buffers((W, H), scene, (0.0, 0.0))
+            dev.sync()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
     steps = args.steps
-    value = total_seg / elapsed / 1e6
-    # for reference: the same frames submitted one per launch (the interactive, lowest-latency way)
-    single = None
-    if world == 1 and B > 1 and args.single_frame_reference:
-        n1 = min(100, args.steps)
-        B, keep = 1, B
-        run_frames(0, 10)
-        fence()
-        t1 = time.perf_counter()
-        run_frames(warm_frames, n1)
-        fence()
-        dt1 = time.perf_counter() - t1
-        B = keep
-        seg1 = np.zeros(n1, np.uint64)
-        dev.call("rt_get_frame_history", n1, seg1.ctypes.data_as(C.c_void_p), None, None)
-        single = {"frames_per_launch": 1, "frames": n1, "ms_per_frame": round(dt1 / n1 * 1e3, 5),
-                  "mrays_per_s": round(float(seg1.sum()) / dt1 / 1e6, 2)}
-    # roofline of the dominant (only) kernel, rank 0's launches
-    k_sec = float(kms.sum()) * 1e-3
-    b_alg = algorithmic_bytes(frame_px * steps, float(seg.sum()), float(rough.sum()))
-    f_alg = algorithmic_flops(frame_px * steps, float(seg.sum()), n_objects)
+    elapsed, blk = head["elapsed"], head["block"]
+    n_objects = len(scene.objects) if args.slots == 0 else args.slots
+    value = head["total_seg"] / elapsed / 1e6
+    # roofline of the dominant kernel (the render kernel), rank 0's launches of the median block
+    launches = blk["launches"]
+    k_sec = blk["kernel_ms"] * 1e-3
+    b_alg = algorithmic_bytes(head["frame_px"] * steps, blk["seg"], blk["rough"])
+    f_alg = algorithmic_flops(head["frame_px"] * steps, blk["seg"], n_objects)
     achieved = b_alg / k_sec / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-    if os.path.exists(tpath) and world == 1:
+    # Measured HBM traffic and issue utilisation come from the committed PMC passes of THIS workload and launch
+    # shape (profiles/traffic_r02.json, collected by tools/profile_round.sh); for any other workload they are null.
+    traffic = traffic_resolve = issue_util = None
+    workload_key = {"width": W, "height": H, "objects": n_objects, "bounces": args.bounces, "sky_width": args.sky,
+                    "frames_per_launch": B, "n_gpus": world}
+    for name in ("traffic_r02.json",):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(tpath):
+            continue
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
+                prof = json.load(f)
         except Exception:
-            traffic = None
+            continue
+        if prof.get("workload_key") == workload_key and steps % B == 0:
+            traffic = prof.get("render_kernel", {}).get("hbm_bytes_per_launch")
+            traffic_resolve = prof.get("resolve_kernel", {}).get("hbm_bytes_per_launch")
+            issue_util = prof.get("render_kernel", {}).get("valu_issue_util")
     out = {
         "metric": "Mrays/s at 1920x1080, 64 spheres, 8 bounces",
         "value": round(value, 2),
@@ -231,8 +303,12 @@ def main():
             "kernel_variant": args.variant,
             "frames_per_launch": B,
             "progressive_count": "frame index k (1-spp frames of a resting camera accumulate, app.rs:208-254)",
+            "timing": "median of %d blocks of %d steps (%.2f s measured, block %.3f..%.3f ms) after %.1f s of untimed "
+                      "launches + %d warm-up steps" % (head["n_blocks"], steps, head["measured_s"], head["dt_min"] * 1e3,
+                                                      head["dt_max"] * 1e3, args.clock_warmup, args.warmup),
             "one_frame_per_launch": single,
-            "segments_per_pixel": round(total_seg / (float(W) * H * steps), 4),
+            "reference_80_slots": slots80,
+            "segments_per_pixel": round(head["total_seg"] / (float(W) * H * steps), 4),
             "mpixels_per_s": round(W * H * steps / elapsed / 1e6, 2),
         },
         "roofline": {
@@ -242,8 +318,10 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
-            "kernel": {2: "render_persistent", 3: "render_blocks", -1: "auto (render_blocks at this size)"}.get(args.variant, "render_tiles"),
-            "avg_launch_ms": round(float(kms.mean()), 5),
+            "traffic_resolve_kernel": traffic_resolve,
+            "kernel": KERNEL_NAMES.get(variant_used, "?"),
+            "avg_launch_ms": round(blk["kernel_ms"] / launches, 5),
+            "resolve_avg_launch_ms": round(blk["resolve_ms"] / launches, 5),
             "launches": launches,
             "alg_bytes_per_launch": round(b_alg / launches, 1),
             "note": "VALU-bound path (SURVEY §8d): see 'valu' for the binding roofline",
@@ -253,10 +331,11 @@ def main():
             "peak": VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(f_alg / k_sec / 1e12 / VALU_PEAK_TFLOPS, 5),
+            "issue_util": issue_util,
             "alg_flops_per_launch": round(f_alg / launches, 1),
-            "kernel_mrays_per_s": round(float(seg.sum()) / k_sec / 1e6, 2),
-            "scan_lane_occupancy": round(float(st.last_segments) / (64.0 * st.last_wave_iterations), 4)
-            if st.last_wave_iterations else None,
+            "kernel_mrays_per_s": round(blk["seg"] / k_sec / 1e6, 2),
+            "scan_lane_occupancy": round(float(head["stats"].last_segments) / (64.0 * head["stats"].last_wave_iterations), 4)
+            if head["stats"].last_wave_iterations else None,
         },
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -269,14 +348,15 @@ def main():
         # the GPU box gives one GPU a share of 16 host cores; never use more than that
         threads = max(1, min(oracle.max_threads(), os.cpu_count() or 1, 16))
         cfg = scene.config_bytes(W, H)
-        oracle.render(objects, count, cfg, jit[args.warmup], 0, sky, rnd, rows=(rows[0], rows[0] + 8),
+        k0 = blk["first"]  # first frame of the median block: its first launch covers frames k0 .. k0+first_n-1
+        oracle.render(objects, count, cfg, jit[k0 % n_jit], 0, sky, rnd, rows=(rows[0], rows[0] + 8),
                       threads=threads, want_hits=False)  # warm the thread pool
         cseg, cdt, frames, first_seg = 0, 0.0, 0, 0
-        first_n = min(B, args.steps)  # frames of the first timed launch
-        while (cdt < 12.0 or frames < first_n) and frames < args.steps:  # a bounded sample: whole frames, ~12 s of wall time
-            k = warm_frames + frames
+        first_n = min(B, steps)
+        while (cdt < 12.0 or frames < first_n) and frames < 512:  # bounded sample: ~12 s of whole frames
+            k = k0 + frames
             c0 = time.perf_counter()
-            fr = oracle.render(objects, count, cfg, jit[k], 0, sky, rnd, rows=rows, threads=threads, want_hits=False)
+            fr = oracle.render(objects, count, cfg, jit[k % n_jit], 0, sky, rnd, rows=rows, threads=threads, want_hits=False)
             cdt += time.perf_counter() - c0
             fs = int(fr.segments[rows[0]:rows[1]].sum())
             first_seg += fs if frames < first_n else 0
@@ -291,8 +371,8 @@ def main():
                       "threads), CPU oracle oracle/rt_oracle.c; the reference itself cannot run here (no "
                       "Rust/wgpu/Vulkan)" % (frames, rows[0], rows[1], W, H, cseg, cdt, threads),
         }
-        # cross-check: the GPU counted the same number of segments for that frame
-        out["cpu_baseline"]["segments_match_gpu"] = bool(args.cpu_rows <= 0 and first_seg == int(seg[0]))
+        # cross-check: the GPU counted the same number of segments for the frames of that launch
+        out["cpu_baseline"]["segments_match_gpu"] = bool(args.cpu_rows <= 0 and first_seg == blk["seg_first_launch"])
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

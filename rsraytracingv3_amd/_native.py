@@ -69,6 +69,8 @@ SIGNATURES = {
     "rt_sync": (_i, [_vp]),
     "rt_read_rgba8": (_i, [_vp, _vp, _sz]),
     "rt_read_rgbf32": (_i, [_vp, _vp, _sz]),
+    "rt_read_rgba8_rows": (_i, [_vp, _u32, _u32, _vp, _sz]),
+    "rt_read_rgbf32_rows": (_i, [_vp, _u32, _u32, _vp, _sz]),
     "rt_read_segments": (_i, [_vp, _vp, _sz]),
     "rt_read_hits": (_i, [_vp, _vp, _sz]),
     "rt_write_history_rgba8": (_i, [_vp, _vp, _sz]),

@@ -138,15 +138,22 @@ class RenderTarget:
     def _local_rows(self) -> int:
         return self.device.stats().local_rows
 
-    def read_rgba8(self) -> np.ndarray:
-        rows = self._local_rows()
-        out = np.empty((rows, self.size[0], 4), np.uint8)
+    def read_rgba8(self, rows: Optional[Tuple[int, int]] = None) -> np.ndarray:
+        """The stored texels; ``rows`` = (first, count) reads that band of local rows only."""
+        if rows is not None:
+            out = np.empty((rows[1], self.size[0], 4), np.uint8)
+            self.device.call("rt_read_rgba8_rows", rows[0], rows[1], out.ctypes.data_as(C.c_void_p), out.nbytes)
+            return out
+        out = np.empty((self._local_rows(), self.size[0], 4), np.uint8)
         self.device.call("rt_read_rgba8", out.ctypes.data_as(C.c_void_p), out.nbytes)
         return out
 
-    def read_rgbf32(self) -> np.ndarray:
-        rows = self._local_rows()
-        out = np.empty((rows, self.size[0], 3), np.float32)
+    def read_rgbf32(self, rows: Optional[Tuple[int, int]] = None) -> np.ndarray:
+        if rows is not None:
+            out = np.empty((rows[1], self.size[0], 3), np.float32)
+            self.device.call("rt_read_rgbf32_rows", rows[0], rows[1], out.ctypes.data_as(C.c_void_p), out.nbytes)
+            return out
+        out = np.empty((self._local_rows(), self.size[0], 3), np.float32)
         self.device.call("rt_read_rgbf32", out.ctypes.data_as(C.c_void_p), out.nbytes)
         return out
 
@@ -271,8 +278,12 @@ class Connection:
     def load_hdri(self, skybox):
         """connection.rs:176-215 — (H, W, 4) float32, row 0 = top, or the path of an .exr file (the
         reference reads ./assets/table_mountain_1_8k.exr)."""
-        if isinstance(skybox, (str, bytes, os.PathLike)):
-            skybox = self.load_image(os.fspath(skybox))[1]
+        if isinstance(skybox, (str, bytes, os.PathLike)):  # decode + upload inside the library (rt_set_skybox_exr)
+            rc = self.device._lib.rt_set_skybox_exr(self.device.handle, os.fsencode(os.fspath(skybox)))
+            if rc != N.RT_OK:
+                text = self.device._lib.rt_exr_last_error() or self.device._lib.rt_last_error(self.device.handle) or b""
+                raise N.RtError(rc, "rt_set_skybox_exr", text.decode(errors="replace"))
+            return
         skybox = np.ascontiguousarray(skybox, np.float32)
         if skybox.ndim != 3 or skybox.shape[2] != 4:
             raise ValueError("skybox must be (H, W, 4) float32")

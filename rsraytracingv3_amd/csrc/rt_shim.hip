@@ -196,15 +196,24 @@ void camera_setup(rt_context *ctx) {
   ctx->cam_neg_up = -up;
 }
 
+// Copies local rows [first_row, first_row + n_rows) of a per-pixel output to the host (n_rows = UINT32_MAX: all).
 template <typename T>
-int read_back(rt_context *ctx, const T *src, void *dst, size_t bytes, size_t elem_bytes, const char *what) {
+int read_back(rt_context *ctx, const T *src, void *dst, size_t bytes, size_t elem_bytes, const char *what,
+              uint32_t first_row = 0, uint32_t n_rows = UINT32_MAX) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!dst) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "%s: dst is NULL", what);
   if (!src) return fail(ctx, RT_ERR_NOT_READY, "%s: output not enabled or no target allocated", what);
-  const size_t need = static_cast<size_t>(ctx->local_rows) * ctx->width * elem_bytes;
+  if (n_rows == UINT32_MAX) n_rows = ctx->local_rows - (first_row <= ctx->local_rows ? first_row : ctx->local_rows);
+  if (first_row > ctx->local_rows || n_rows > ctx->local_rows - first_row)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "%s: rows %u..%u of %u local rows", what, first_row, first_row + n_rows,
+                ctx->local_rows);
+  const size_t row_bytes = static_cast<size_t>(ctx->width) * elem_bytes;
+  const size_t need = static_cast<size_t>(n_rows) * row_bytes;
   if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "%s: %zu bytes given, %zu expected", what, bytes, need);
+  if (need == 0) return RT_OK;
   RT_HIP(ctx, hipSetDevice(ctx->device));
-  RT_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipMemcpyAsync(dst, reinterpret_cast<const unsigned char *>(src) + first_row * row_bytes, bytes,
+                             hipMemcpyDeviceToHost, ctx->stream));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RT_OK;
 }
@@ -793,6 +802,14 @@ int rt_read_rgba8(rt_context *ctx, void *dst, size_t bytes) {  // caller-bound b
 }
 int rt_read_rgbf32(rt_context *ctx, float *dst, size_t bytes) {
   return read_back(ctx, ctx ? (ctx->ext_rgba8 ? ctx->ext_rgbf32 : ctx->d_rgbf32) : nullptr, dst, bytes, 12, "rt_read_rgbf32");
+}
+int rt_read_rgba8_rows(rt_context *ctx, uint32_t first_row, uint32_t n_rows, void *dst, size_t bytes) {
+  return read_back(ctx, ctx ? (ctx->ext_rgba8 ? ctx->ext_rgba8 : ctx->d_rgba8) : nullptr, dst, bytes, 4, "rt_read_rgba8_rows",
+                   first_row, n_rows);
+}
+int rt_read_rgbf32_rows(rt_context *ctx, uint32_t first_row, uint32_t n_rows, float *dst, size_t bytes) {
+  return read_back(ctx, ctx ? (ctx->ext_rgba8 ? ctx->ext_rgbf32 : ctx->d_rgbf32) : nullptr, dst, bytes, 12,
+                   "rt_read_rgbf32_rows", first_row, n_rows);
 }
 int rt_read_segments(rt_context *ctx, uint32_t *dst, size_t bytes) {
   return read_back(ctx, ctx ? ctx->d_segments : nullptr, dst, bytes, 4, "rt_read_segments");

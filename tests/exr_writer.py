@@ -232,10 +232,26 @@ def _piz(planes, width, lines) -> bytes:
 
 
 # ---- file --------------------------------------------------------------------------------------------
+def _encode_chunk(job):
+    """One chunk's payload (module level so that a process pool can run it)."""
+    compression, force_raw, w, lines, planes = job
+    raw = b"".join(arr[y].tobytes() for y in range(lines) for arr, _ in planes)
+    if compression == NONE or force_raw:
+        data = raw
+    elif compression == RLE:
+        data = _rle(_predict_and_split(raw))
+    elif compression in (ZIPS, ZIP):
+        data = zlib.compress(_predict_and_split(raw))
+    else:
+        data = _piz(planes, w, lines)
+    return raw if len(data) >= len(raw) else data
+
+
 def write_exr(path, channels, compression=ZIP, display_window=None, data_origin=(0, 0), decreasing_y=False,
-              force_raw_chunks=False):
+              force_raw_chunks=False, workers=1):
     """channels: {name: (2-D array, "half" | "float" | "uint")}, all of one shape (the data window).
-    display_window: (xmin, ymin, xmax, ymax), default = the data window placed at data_origin."""
+    display_window: (xmin, ymin, xmax, ymax), default = the data window placed at data_origin.
+    workers > 1 encodes the chunks in a process pool (the pure-Python PIZ encoder needs it at 8k)."""
     names = sorted(channels)
     h, w = channels[names[0]][0].shape
     x0, y0 = data_origin
@@ -260,21 +276,16 @@ def write_exr(path, channels, compression=ZIP, display_window=None, data_origin=
     header += _attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
     header += b"\0"
     step = LINES[compression]
-    chunks = []
-    for r0 in range(0, h, step):
-        r1 = min(r0 + step, h)
-        raw = b"".join(arr[y].tobytes() for y in range(r0, r1) for arr, _ in arrays)
-        if compression == NONE or force_raw_chunks:
-            data = raw
-        elif compression == RLE:
-            data = _rle(_predict_and_split(raw))
-        elif compression in (ZIPS, ZIP):
-            data = zlib.compress(_predict_and_split(raw))
-        else:
-            data = _piz([(arr[r0:r1], size) for arr, size in arrays], w, r1 - r0)
-        if len(data) >= len(raw):
-            data = raw
-        chunks.append(struct.pack("<ii", y0 + r0, len(data)) + data)
+    starts = list(range(0, h, step))
+    jobs = ((compression, force_raw_chunks, w, min(r0 + step, h) - r0,
+             [(arr[r0:min(r0 + step, h)], size) for arr, size in arrays]) for r0 in starts)
+    if workers > 1:
+        import multiprocessing
+        with multiprocessing.get_context("fork").Pool(workers) as pool:
+            payloads = pool.map(_encode_chunk, jobs, chunksize=1)
+    else:
+        payloads = [_encode_chunk(j) for j in jobs]
+    chunks = [struct.pack("<ii", y0 + r0, len(data)) + data for r0, data in zip(starts, payloads)]
     table_at = len(header)
     offsets, pos = [0] * len(chunks), table_at + 8 * len(chunks)
     order = range(len(chunks) - 1, -1, -1) if decreasing_y else range(len(chunks))
@@ -284,3 +295,22 @@ def write_exr(path, channels, compression=ZIP, display_window=None, data_origin=
         body += chunks[i]
     with open(path, "wb") as f:
         f.write(header + struct.pack("<%dQ" % len(chunks), *offsets) + body)
+
+
+if __name__ == "__main__":
+    # python tests/exr_writer.py skybox WIDTH PATH [piz|zip|zips|rle|none] [workers]
+    # Writes rsraytracingv3_amd.synth.procedural_skybox(WIDTH, WIDTH/2) as a HALF R,G,B file.  Run as a child
+    # process by the config-5 GPU test: this process never touches the GPU, so its fork pool is safe.
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from rsraytracingv3_amd import synth
+    if len(sys.argv) < 4 or sys.argv[1] != "skybox":
+        raise SystemExit(__doc__)
+    width, out_path = int(sys.argv[2]), sys.argv[3]
+    comp = {"piz": PIZ, "zip": ZIP, "zips": ZIPS, "rle": RLE, "none": NONE}[sys.argv[4] if len(sys.argv) > 4 else "piz"]
+    n_workers = int(sys.argv[5]) if len(sys.argv) > 5 else (os.cpu_count() or 1)
+    img = synth.procedural_skybox(width, width // 2)
+    write_exr(out_path, {"R": (img[..., 0], "half"), "G": (img[..., 1], "half"), "B": (img[..., 2], "half")}, comp,
+              workers=n_workers)
+    print("wrote %s: %dx%d, %d bytes" % (out_path, width, width // 2, os.path.getsize(out_path)))
