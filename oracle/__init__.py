@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY — imported by ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py``; never by the ``rsraytracingv3_amd`` package.
-Parity status of the oracle itself: *unpinned* (the reference has no tests or golden
+Parity status of the oracle itself: pinned on geometry and emission by the reference's screenshot
+(``tests/test_screenshot_pin.py``), texel values otherwise *unpinned* (the reference has no tests or golden
 vectors and cannot be built here — see the header of ``rt_oracle.c``).
 """
 from __future__ import annotations

@@ -4,13 +4,21 @@
  * link or call this file; only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py do, and only as the checker / reported baseline.
  *
- * PARITY STATUS: "parity unpinned".  The reference (arlohb/RSRayTracingV3 @ v2)
- * has no tests, golden images or known-answer vectors, and it can be neither
- * compiled nor run in this environment (no Rust toolchain, no shader compiler,
- * no Vulkan).  This restatement follows the HLSL text function
- * by function (citations below are relative to /root/reference/src/) and is
- * pinned by hand-derivable known-answer tests (tests/test_oracle_kat.py) and
- * byte-layout KATs derived from the Rust writers (tests/test_layout.py).
+ * PARITY STATUS: pinned on geometry and emission by the one output the reference
+ * holds, texel values otherwise "parity unpinned".  The reference
+ * (arlohb/RSRayTracingV3 @ v2) has no tests, golden images or known-answer
+ * vectors, and it can be neither compiled nor run in this environment (no Rust
+ * toolchain, no shader compiler, no Vulkan).  Its screenshot,
+ * however, contains the unscaled 1000x900 texels its shader stored
+ * (tests/golden/make_screenshot_fixture.py): tests/test_screenshot_pin.py checks
+ * this restatement against them — horizon row, registration of every sphere
+ * silhouette to +-1..2 px, saturation of every emissive sphere in exactly its
+ * emission channels.  The HDRI, jitter and noise texture of that run are unknown,
+ * so colours cannot be compared texel by texel.  Beyond that the restatement
+ * follows the HLSL text function by function (citations below are relative to
+ * /root/reference/src/) and is pinned by hand-derivable known-answer tests
+ * (tests/test_oracle_kat.py) and byte-layout KATs derived from the Rust writers
+ * (tests/test_layout.py).
  *
  * Arithmetic: IEEE-754 binary32 throughout, built with -ffp-contract=off; every
  * fused multiply-add is an explicit fmaf().  Where the HLSL leaves a choice

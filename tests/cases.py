@@ -49,8 +49,13 @@ def inputs(sky_w=256, sky_h=128, rnd_seed=1):
 
 def reference_default_scene(reflection_limit: int = 3) -> Scene:
     """The reference's start-up scene (scene.rs:81-89, seed 42) regenerated on its own random stream,
-    seen from the camera of its screenshot."""
+    seen from the camera of its screenshot: position as its panel shows, rotation (shown as 0.5 / -0.3, one
+    decimal) as fitted inside that rounding interval by tests/golden/make_screenshot_fixture.py."""
+    import json
+    import os
     s = Scene.random_spheres_default_config()
     s.reflection_limit = reflection_limit
-    s.camera = Camera((34.4, 37.3, 105.5), (0.5, -0.3, 0.0), 70.0)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_screenshot_panel.json")) as f:
+        cam = json.load(f)["camera"]
+    s.camera = Camera(tuple(cam["position"]), tuple(cam["rotation"]), cam["fov"])
     return s
