@@ -175,6 +175,10 @@ RT355_API int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t by
 
 RT355_API int rt_get_device_buffers(rt_context *ctx, rt_device_buffers *out);
 RT355_API int rt_get_stats(rt_context *ctx, rt_stats *out);
+/* Diagnostic: the 16 per-launch counter words of the last launch, summed over their shards — {segments, rough
+ * hits, wave iterations, cull mismatches, then 8 per-phase cycle sums that only the profiling build
+ * (make -C csrc prof) fills, 4 unused}. */
+RT355_API int rt_get_counter_words(rt_context *ctx, uint64_t *out16);
 /* Per-frame totals and HIP-event kernel times of the most recent n frames (oldest first;
  * n <= 512).  Any output pointer may be NULL.  Waits for the stream. */
 RT355_API int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segments, uint64_t *rough_hits,

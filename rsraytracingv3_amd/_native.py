@@ -76,6 +76,7 @@ SIGNATURES = {
     "rt_write_history_rgba8": (_i, [_vp, _vp, _sz]),
     "rt_get_device_buffers": (_i, [_vp, C.POINTER(RtDeviceBuffers)]),
     "rt_get_stats": (_i, [_vp, C.POINTER(RtStats)]),
+    "rt_get_counter_words": (_i, [_vp, _vp]),
     "rt_get_frame_history": (_i, [_vp, _u32, _vp, _vp, _vp]),
     "rt_get_resolve_history": (_i, [_vp, _u32, _vp]),
     "rt_set_stream": (_i, [_vp, _vp]),

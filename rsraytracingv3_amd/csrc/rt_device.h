@@ -1,16 +1,8 @@
 // rt_device.h — data shared between the C-ABI shim (host) and the gfx950 kernels.
 //
 // HBM layout of one context (DESIGN.md "Data layout"):
-//   compiled scene   one allocation of float4 records, re-laid out from the 112-byte AoS wire
-//                    objects (objects.rs:202-214) into what the kernel reads:
-//                      sph[n_sph_pad]  {cx, cy, cz, r*r}        scanned by every ray segment (padded
-//                                                               with never-hit records),
-//                                                               staged into LDS per workgroup
-//                      sph_obj[n_sph]  original object index    (ascending; tie-break D10)
-//                      pl_a[n_pl]      {cx, cy, cz, half_size}
-//                      pl_b[n_pl]      {nx, ny, nz, bits(object index)}
-//                      mat0[n_obj]     {2*colour.rgb, roughness}         fetched for the winner only
-//                      mat1[n_obj]     {emission*strength .rgb, 1/(phong_alpha+1)}
+//   compiled scene   one allocation of float4 records re-laid out from the 112-byte AoS wire objects
+//                    (objects.rs:202-214): see DeviceScene below
 //   skybox           RGBA32F, row-major, row 0 = top (connection.rs:187-212)
 //   random           R32F row-major (random_texture.rs:30-39), double buffered
 //   rgba8            local_rows x W x 4 B: the Rgba8UnormSrgb target AND its own history
@@ -28,16 +20,33 @@ constexpr uint32_t kTotalShardStride = 16;  // u64 words between shards (128 B)
 constexpr uint32_t kSphBatch = 8;  // sphere records consumed per scan-loop trip
 constexpr uint32_t kMaxBatch = 64;  // frames one launch can render (rt_render_frames)
 
+// The compiled scene is ONE allocation of float4 records, laid out exactly as the kernels stage it into LDS
+// ("scene image"); n = n_sph_pad, p = n_pl:
+//   [0, n)            sph     {cx, cy, cz, r*r}, padded with never-hit records
+//   [n, 2n)           smat0   {2*colour.rgb, roughness}            of the sphere in that slot
+//   [2n, 3n)          smat1   {emission*strength .rgb, 1/(phong_alpha+1)}
+//   [3n, 3n+p)        pl_a    {cx, cy, cz, half_size}
+//   [3n+p, 3n+2p)     pl_b    {nx, ny, nz, bits(object index)}
+//   [3n+2p, 3n+3p)    pmat0   as smat0, of the plane
+//   [3n+3p, 3n+4p)    pmat1
+//   [3n+4p, ...)      sph_obj original object index per sphere slot (ints, 4 per record; -1 in the padding)
+// Materials are indexed by SLOT, so the winner's material needs no object index first (one dependent
+// gather less per shaded hit), and for scenes of up to kImageLdsRecords records the whole image lives in LDS.
 struct DeviceScene {
-  const float4 *sph;
-  const int *sph_obj;
-  const float4 *pl_a;
-  const float4 *pl_b;
-  const float4 *mat0;
-  const float4 *mat1;
+  const float4 *image;
   uint32_t n_sph, n_pl, n_obj;
-  uint32_t n_sph_pad;  // records in sph[]: n_sph rounded up to kSphBatch, plus one batch of read-ahead
+  uint32_t n_sph_pad;      // records in sph[]: n_sph rounded up to kSphBatch, plus one batch of read-ahead
+  uint32_t image_records;  // float4 records in the whole image
+  __host__ __device__ const float4 *sph() const { return image; }
+  __host__ __device__ uint32_t off_smat0() const { return n_sph_pad; }
+  __host__ __device__ uint32_t off_smat1() const { return 2u * n_sph_pad; }
+  __host__ __device__ uint32_t off_pl_a() const { return 3u * n_sph_pad; }
+  __host__ __device__ uint32_t off_pl_b() const { return 3u * n_sph_pad + n_pl; }
+  __host__ __device__ uint32_t off_pmat0() const { return 3u * n_sph_pad + 2u * n_pl; }
+  __host__ __device__ uint32_t off_pmat1() const { return 3u * n_sph_pad + 3u * n_pl; }
+  __host__ __device__ uint32_t off_sph_obj() const { return 3u * n_sph_pad + 4u * n_pl; }
 };
+constexpr uint32_t kImageLdsRecords = 1024;  // 16 KB: scenes up to ~300 spheres are staged whole
 
 struct FrameParams {
   uint32_t width, height;      // full frame (Config.width/height, scene.rs:267-268)

@@ -62,6 +62,30 @@ __device__ __forceinline__ float sqrt_rn(float x) {
   return r;
 }
 
+// Diagnostic build only (make prof: -DRT_PROFILE_PHASES): per-wave s_memtime deltas of the phases of
+// render_blocks, summed into words 4.. of the launch's counter shard.  Compiles to nothing otherwise.
+#ifdef RT_PROFILE_PHASES
+#define RT_PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_PH_MARK(k)                                                \
+  {                                                                  \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
+    ph_acc[k] += now_ - ph_t;                                        \
+    ph_t = now_;                                                     \
+  }
+#define RT_PH_FLUSH(shard)                                                                         \
+  if ((threadIdx.x & 63u) == 0)                                                                    \
+    for (int k_ = 0; k_ < 8; ++k_)                                                                 \
+      if (ph_acc[k_]) atomicAdd(&(shard)[4 + k_], ph_acc[k_]);
+#define RT_PH_PARAMS , unsigned long long &ph_t, unsigned long long (&ph_acc)[8]
+#define RT_PH_ARGS , ph_t, ph_acc
+#else
+#define RT_PH_DECL
+#define RT_PH_MARK(k)
+#define RT_PH_FLUSH(shard)
+#define RT_PH_PARAMS
+#define RT_PH_ARGS
+#endif
+
 struct Rng {
   float seed, px, py;  // random.hlsl:1-2
 };
@@ -75,25 +99,23 @@ __device__ __forceinline__ size_t rng_texel(const FrameParams &fp, const Rng &rn
   const uint32_t i = texel_index(cx, fp.rnd_w), j = texel_index(cy, fp.rnd_h);
   return static_cast<size_t>(j) * fp.rnd_w + i;
 }
-// rng_advance: rng_seed = (rng_seed + x * 532.3412) % 600.  The seed stays in [0, 1200) for texture
+// rng_next_seed: rng_seed = (rng_seed + x * 532.3412) % 600.  The seed stays in [0, 1200) for texture
 // values in [0, 1), where one conditional subtraction is the exact remainder; anything else takes fmodf.
-__device__ __forceinline__ void rng_advance(Rng &rng, float x) {
-  float s = fmaf(x, 532.3412f, rng.seed);
+__device__ __forceinline__ float rng_next_seed(float seed, float x) {
+  float s = fmaf(x, 532.3412f, seed);
   if (s >= 0.0f && s < 1200.0f) {
     s = (s >= 600.0f) ? s - 600.0f : s;
   } else {
     s = fmodf(s, 600.0f);
   }
-  rng.seed = s;
+  return s;
 }
 
-// random.hlsl:13-43 with the per-object constant 1/(phong_alpha+1) precomputed (inv_exp).  x1 is the
-// first random() value, fetched by the caller before the object scan (its texel depends only on the
-// RNG state at the start of the segment).
-__device__ __forceinline__ f3 hemisphere(const FrameParams &fp, Rng &rng, f3 n, float inv_exp, float x1) {
-  rng_advance(rng, x1);
-  const float x2 = fp.rnd[rng_texel(fp, rng)];
-  rng_advance(rng, x2);
+// random.hlsl:13-43 with the per-object constant 1/(phong_alpha+1) precomputed (inv_exp).  x1 and x2 are the
+// two random() values, both requested by the caller during the object scan: x1's texel depends only on the
+// RNG state at the start of the segment, x2's on that state advanced by x1 (= seed1).
+__device__ __forceinline__ f3 hemisphere(Rng &rng, f3 n, float inv_exp, float x1, float x2, float seed1) {
+  rng.seed = rng_next_seed(seed1, x2);
   const float cos_theta = pow_spec(x1, inv_exp);
   const float sin_theta = sqrtf(fmaf(-cos_theta, cos_theta, 1.0f));
   const float phi = kTwoPi * x2;
@@ -115,6 +137,29 @@ __device__ __forceinline__ f3 sample_hdri(const FrameParams &fp, f3 d) {
   return mk3(t.x, t.y, t.z);
 }
 
+// Where a kernel reads the scene image from (rt_device.h): LDS for what it staged, global memory for the rest.
+struct SceneView {
+  const float4 *sph, *smat0, *smat1, *pl_a, *pl_b, *pmat0, *pmat1;
+  const int *sph_obj;
+  uint32_t n_sph_pad, n_pl;
+};
+// `sph_base`: record 0 of the sphere array; `rest_base`: record 0 of an image that holds everything else
+// (the two are the same pointer when the whole image was staged).
+__device__ __forceinline__ SceneView make_view(const DeviceScene &sc, const float4 *sph_base, const float4 *rest_base) {
+  SceneView v;
+  v.sph = sph_base;
+  v.smat0 = rest_base + sc.off_smat0();
+  v.smat1 = rest_base + sc.off_smat1();
+  v.pl_a = rest_base + sc.off_pl_a();
+  v.pl_b = rest_base + sc.off_pl_b();
+  v.pmat0 = rest_base + sc.off_pmat0();
+  v.pmat1 = rest_base + sc.off_pmat1();
+  v.sph_obj = reinterpret_cast<const int *>(rest_base + sc.off_sph_obj());
+  v.n_sph_pad = sc.n_sph_pad;
+  v.n_pl = sc.n_pl;
+  return v;
+}
+
 struct Hit {
   float t;
   int obj;    // original object index, -1 = miss
@@ -134,9 +179,11 @@ struct SphereHit {
 };
 
 // The sphere part of ray.hlsl:97-107, one ray per lane (call with the lanes that carry a ray).
-__device__ __forceinline__ SphereHit scan_spheres(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d) {
-  uint32_t best_key = kNoHitKey;
-  int slot = -1;
+// Records [begin, end) (multiples of 8; up to end + 3 is read), continuing from `acc`.
+__device__ __forceinline__ SphereHit scan_spheres(const float4 *__restrict__ sph, uint32_t begin, uint32_t end, f3 o, f3 d,
+                                                  SphereHit acc = SphereHit{kNoHitKey, -1}) {
+  uint32_t best_key = acc.key;
+  int slot = acc.slot;
   // One sphere of ray.hlsl:53-68.  q = discriminant/4 and dn = b/2 (exact power-of-two scalings of
   // the reference's b, c, discriminant), so t = -dn - sqrt(q) has the bits of (-b - sqrt(disc))/(2a).
   // A sphere can only be accepted when q >= 0 and dn < 0 (then t > 0); min(q, -dn) >= 0 is a
@@ -167,9 +214,8 @@ __device__ __forceinline__ SphereHit scan_spheres(const DeviceScene &sc, const f
   }
   // Two batches of 4 per trip, each computed while the next one's LDS reads are in flight
   // (n_sph_pad is a multiple of 8 plus 8 readable never-hit records).
-  const uint32_t n = sc.n_sph_pad - kSphBatch;
-  float4 g0 = sph[0], g1 = sph[1], g2 = sph[2], g3 = sph[3];
-  for (uint32_t i = 0; i < n; i += 8) {
+  float4 g0 = sph[begin], g1 = sph[begin + 1], g2 = sph[begin + 2], g3 = sph[begin + 3];
+  for (uint32_t i = begin; i < end; i += 8) {
     const float4 h0 = sph[i + 4], h1 = sph[i + 5], h2 = sph[i + 6], h3 = sph[i + 7];
     RT_SPHERE_BATCH(g0, g1, g2, g3, i)
     g0 = sph[i + 8];
@@ -191,7 +237,7 @@ __device__ __forceinline__ SphereHit scan_spheres(const DeviceScene &sc, const f
 // Rays are handed to lane groups and results handed back with ds_permute/ds_bpermute; every lane of
 // the wave must call this (full EXEC), `alive` says which lanes own a ray.  A 16-ray wave costs 18
 // sphere steps instead of 72.
-__device__ __forceinline__ SphereHit scan_spheres_coop(const DeviceScene &sc, const float4 *__restrict__ sph, f3 o, f3 d,
+__device__ __forceinline__ SphereHit scan_spheres_coop(const float4 *__restrict__ sph, uint32_t n_sph_pad, f3 o, f3 d,
                                                        bool alive, unsigned long long live, uint32_t n_live_rays) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t shift = n_live_rays <= 4u ? 4u : (n_live_rays <= 8u ? 3u : (n_live_rays <= 16u ? 2u : 1u));  // log2(G), wave-uniform
@@ -218,7 +264,7 @@ __device__ __forceinline__ SphereHit scan_spheres_coop(const DeviceScene &sc, co
   rd.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.z)));
   uint32_t key = kNoHitKey;
   int slot = -1;
-  const uint32_t n = sc.n_sph_pad - kSphBatch;  // records that can hit (the tail records never do)
+  const uint32_t n = n_sph_pad - kSphBatch;  // records that can hit (the tail records never do)
   for (uint32_t base = 0; base < n; base += G) {
     const uint32_t j = base + sub;             // < n_sph_pad: n is a multiple of 8 and 8 more are readable
     const float4 g = sph[j];
@@ -282,16 +328,16 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
 }
 
 // The rest of ray.hlsl:97-107: sphere result -> Hit, then the planes (ray.hlsl:69-94).
-__device__ __forceinline__ Hit finish_hit(const DeviceScene &sc, SphereHit sh, f3 o, f3 d) {
+__device__ __forceinline__ Hit finish_hit(const SceneView &sv, SphereHit sh, f3 o, f3 d) {
   const float best = __uint_as_float(sh.key + kEpsBits);
   const int slot = sh.slot;
   Hit h;
   h.t = best;
   h.slot = slot;
   h.plane = false;
-  h.obj = (slot >= 0) ? sc.sph_obj[slot] : -1;
-  for (uint32_t j = 0; j < sc.n_pl; ++j) {
-    const float4 a = sc.pl_a[j], b = sc.pl_b[j];
+  h.obj = (slot >= 0) ? sv.sph_obj[slot] : -1;
+  for (uint32_t j = 0; j < sv.n_pl; ++j) {
+    const float4 a = sv.pl_a[j], b = sv.pl_b[j];
     const f3 c = mk3(a.x, a.y, a.z), nrm = mk3(b.x, b.y, b.z);
     const int idx = static_cast<int>(f2u(b.w));
     const float den = dot3(d, nrm);
@@ -342,13 +388,14 @@ __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, ui
   s.rough = 0;
 }
 
-// shade() of one iteration of frag.hlsl:36-43 for the hit `h`; x1 is the first random() texel value,
-// requested before the scan.  Returns whether the loop goes on.
-// DEFER_SKY: on a miss only mark the path; its skybox texel is fetched in path_end (pays where
-// path_end runs once per wave with all finished lanes, i.e. the plain tile kernel).
+// shade() of one iteration of frag.hlsl:36-43 for the hit `h`; x1, x2 are the two random() texel values
+// requested during the scan (used if the hit is rough), seed1 the RNG state between them.  Returns whether the
+// loop goes on.
+// DEFER_SKY: on a miss only mark the path; its skybox texel is fetched in path_end, together with the other
+// finished lanes of the wave instead of a few lanes at a time after every bounce.
 template <bool DEFER_SKY>
-__device__ __forceinline__ bool path_shade(const DeviceScene &sc, const float4 *__restrict__ sph,
-                                           const FrameParams &fp, Path &s, const Hit h, const float x1) {
+__device__ __forceinline__ bool path_shade(const SceneView &sv, const FrameParams &fp, Path &s, const Hit h,
+                                           const float x1, const float x2, const float seed1) {
   if (fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
   s.seg += 1;
   if (h.obj < 0) {  // frag.hlsl:14-17: miss -> skybox, energy 0, loop ends (|0| < EPSILON)
@@ -361,19 +408,23 @@ __device__ __forceinline__ bool path_shade(const DeviceScene &sc, const float4 *
   }
   const f3 pos = fma3(s.d, h.t, s.o);
   f3 nrm;
+  float4 m0, m1;  // materials by slot: no object index needed first
   if (h.plane) {
-    const float4 b = sc.pl_b[h.slot];
+    const float4 b = sv.pl_b[h.slot];
     nrm = mk3(b.x, b.y, b.z);  // ray.hlsl:43-45: stored normal, not renormalised
+    m0 = sv.pmat0[h.slot];
+    m1 = sv.pmat1[h.slot];
   } else {
-    const float4 g = sph[h.slot];
+    const float4 g = sv.sph[h.slot];
+    m0 = sv.smat0[h.slot];
+    m1 = sv.smat1[h.slot];
     nrm = normalize3(pos - mk3(g.x, g.y, g.z));
   }
-  const float4 m0 = sc.mat0[h.obj], m1 = sc.mat1[h.obj];
   s.o = fma3(nrm, 0.001f, pos);                   // frag.hlsl:21
   const float k = 2.0f * dot3(nrm, s.d);          // reflect(), frag.hlsl:23
   f3 nd = fma3(nrm, -k, s.d);
   if (m0.w != 0.0f) {                             // random.hlsl:26-28
-    nd = hemisphere(fp, s.rng, nd, m1.w, x1);
+    nd = hemisphere(s.rng, nd, m1.w, x1, x2, seed1);
     s.rough += 1;
   }
   s.d = nd;
@@ -387,45 +438,57 @@ __device__ __forceinline__ bool path_shade(const DeviceScene &sc, const float4 *
   return s.seg < fp.reflection_limit;
 }
 
-// One iteration of frag.hlsl:36-43 (ray_intersect + shade) for the calling lanes (one ray each).
-template <bool DEFER_SKY>
-__device__ __forceinline__ bool path_step(const DeviceScene &sc, const float4 *__restrict__ sph,
-                                          const FrameParams &fp, Path &s) {
-  // Requested now, used after the scan if the hit is rough: the gather's latency (an L2 round trip)
-  // hides under the object scan instead of heading the shading chain.
-  const float x1 = fp.rnd[rng_texel(fp, s.rng)];
-  const Hit h = finish_hit(sc, scan_spheres(sc, sph, s.o, s.d), s.o, s.d);
-  return path_shade<DEFER_SKY>(sc, sph, fp, s, h, x1);
-}
-
-// The same for a whole wave (every lane calls it; `alive` = this lane carries a ray): picks the
+// One iteration of frag.hlsl:36-43 (ray_intersect + shade) for a whole wave (every lane calls it; `alive` = this
+// lane carries a ray).  The first random() texel is requested before the scan and used after it if the hit is
+// rough: the gather's latency (an L2 round trip) hides under the object scan.  Picks the
 // wave-cooperative scan when at most 32 lanes are live.  Returns the lane's new `alive`.
 template <bool DEFER_SKY>
-__device__ __forceinline__ bool path_step_wave(const DeviceScene &sc, const float4 *__restrict__ sph,
-                                               const FrameParams &fp, Path &s, bool alive,
-                                               const unsigned long long *__restrict__ primary_mask = nullptr,
-                                               const unsigned long long *__restrict__ primary_mask2 = nullptr) {
+__device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameParams &fp, Path &s, bool alive,
+                                               const unsigned long long *__restrict__ primary_mask,
+                                               const unsigned long long *__restrict__ primary_mask2 RT_PH_PARAMS) {
   const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
   const uint32_t n_live = static_cast<uint32_t>(__popcll(live));
   if (n_live == 0u) return false;
+  // Both random() texels of a rough hit are requested during the scan, whether or not the hit turns out rough
+  // (random.hlsl:4-11: the second texel's address needs the first one's value, nothing else): their L2 round
+  // trips hide under the object scan instead of heading the shading chain one after the other.
+  float x1 = 0.0f, x2 = 0.0f, seed1 = 0.0f;
+  if (alive) x1 = fp.rnd[rng_texel(fp, s.rng)];
+#define RT_REQUEST_X2                                          \
+  if (alive) {                                                 \
+    seed1 = rng_next_seed(s.rng.seed, x1);                     \
+    x2 = fp.rnd[rng_texel(fp, Rng{seed1, s.rng.px, s.rng.py})]; \
+  }
   if (primary_mask != nullptr) {  // wave-uniform: all live lanes carry primary rays of one tile
     if (alive) {
-      const float x1 = fp.rnd[rng_texel(fp, s.rng)];
-      const SphereHit sh = scan_spheres_listed(sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
+      const SphereHit sh = scan_spheres_listed(sv.sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
       if (fp.cull_check) {  // self-check build of the frame: the full scan must agree
-        const SphereHit full = scan_spheres(sc, sph, s.o, s.d);
+        const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
         if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
       }
-      alive = path_shade<DEFER_SKY>(sc, sph, fp, s, finish_hit(sc, sh, s.o, s.d), x1);
+      RT_REQUEST_X2
+      alive = path_shade<DEFER_SKY>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     }
+    RT_PH_MARK(0)
   } else if (n_live <= 32u) {
-    float x1 = 0.0f;
-    if (alive) x1 = fp.rnd[rng_texel(fp, s.rng)];
-    const SphereHit sh = scan_spheres_coop(sc, sph, s.o, s.d, alive, live, n_live);
-    if (alive) alive = path_shade<DEFER_SKY>(sc, sph, fp, s, finish_hit(sc, sh, s.o, s.d), x1);
-  } else if (alive) {
-    alive = path_step<DEFER_SKY>(sc, sph, fp, s);
+    const SphereHit sh = scan_spheres_coop(sv.sph, sv.n_sph_pad, s.o, s.d, alive, live, n_live);
+    RT_PH_MARK(2)
+    RT_REQUEST_X2
+    if (alive) alive = path_shade<DEFER_SKY>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+    RT_PH_MARK(3)
+  } else {
+    if (alive) {
+      // the second texel is requested half-way through the scan: the first has arrived by then
+      const uint32_t n = sv.n_sph_pad - kSphBatch, half = (n >> 1) & ~7u;
+      SphereHit sh = scan_spheres(sv.sph, 0u, half, s.o, s.d);
+      RT_REQUEST_X2
+      sh = scan_spheres(sv.sph, half, n, s.o, s.d, sh);
+      RT_PH_MARK(1)
+      alive = path_shade<DEFER_SKY>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+    }
+    RT_PH_MARK(3)
   }
+#undef RT_REQUEST_X2
   return alive;
 }
 
@@ -502,14 +565,18 @@ __device__ __forceinline__ TilePos tile_pos(const FrameParams &fp, uint32_t tile
   return t;
 }
 
-template <bool GEOM_LDS>
+// STAGE: 2 = the whole scene image staged into LDS, 1 = only the sphere records (scenes of hundreds of
+// spheres), 0 = nothing (scenes beyond a workgroup's LDS): everything else is read from global memory.
+template <int STAGE>
 __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FrameParams fp) {
-  extern __shared__ float4 lds_sph[];
-  if (GEOM_LDS) {
-    for (uint32_t i = threadIdx.x; i < sc.n_sph_pad; i += kBlock) lds_sph[i] = sc.sph[i];
+  extern __shared__ float4 lds_image[];
+  if (STAGE != 0) {
+    const uint32_t n = STAGE == 2 ? sc.image_records : sc.n_sph_pad;
+    for (uint32_t i = threadIdx.x; i < n; i += kBlock) lds_image[i] = sc.image[i];
     __syncthreads();
   }
-  const float4 *sph = GEOM_LDS ? lds_sph : sc.sph;
+  const SceneView sv = make_view(sc, STAGE != 0 ? lds_image : sc.image, STAGE == 2 ? lds_image : sc.image);
+  RT_PH_DECL
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
@@ -530,9 +597,9 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
     alive = fp.reflection_limit != 0u;
   }
   if (fp.tile_masks != nullptr && __builtin_amdgcn_ballot_w64(alive) != 0ull)
-    alive = path_step_wave<true>(sc, sph, fp, s, alive, fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words,
-                                 fp.tile_masks + static_cast<size_t>(tiles_x + tp.row) * fp.mask_words);
-  while (__builtin_amdgcn_ballot_w64(alive) != 0ull) alive = path_step_wave<true>(sc, sph, fp, s, alive);
+    alive = path_step_wave<true>(sv, fp, s, alive, fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words,
+                                 fp.tile_masks + static_cast<size_t>(tiles_x + tp.row) * fp.mask_words RT_PH_ARGS);
+  while (__builtin_amdgcn_ballot_w64(alive) != 0ull) alive = path_step_wave<true>(sv, fp, s, alive, nullptr, nullptr RT_PH_ARGS);
   if (valid) {
     path_end<true>(fp, s);
     seg = s.seg;
@@ -558,9 +625,9 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   // (program order), so no write can pass a read of the value it replaces — also on iterations that
   // do not pack and therefore have no second barrier.
   __shared__ unsigned int wave_count[2][NW];
-  float4 *lds_sph = lds_all;
-  float4 *xchg = lds_all + sc.n_sph_pad;  // kXchgPaths paths x 4 float4
-  for (uint32_t i = threadIdx.x; i < sc.n_sph_pad; i += NW * 64) lds_sph[i] = sc.sph[i];
+  float4 *xchg = lds_all + sc.image_records;  // kXchgPaths paths x 4 float4, behind the staged scene image
+  for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
+  const SceneView sv = make_view(sc, lds_all, lds_all);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
@@ -579,10 +646,12 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   if ((x < fp.width) & (lrow < fp.local_rows) & (tp.frame < fp.batch)) {
     path_begin(fp, x, lrow, tp.frame, s);
     alive = fp.reflection_limit != 0u;
-    if (!alive) path_end(fp, s);
+    if (!alive) path_end<true>(fp, s);
   }
   uint32_t live_waves = NW;
+  RT_PH_DECL
   __syncthreads();  // sphere records staged
+  RT_PH_MARK(7)
   const unsigned long long *primary_mask =
       fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words : nullptr;
   const unsigned long long *primary_mask2 =
@@ -594,10 +663,10 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   for (;;) {
     {
       const bool was = alive;
-      alive = path_step_wave<false>(sc, lds_sph, fp, s, alive, primary_mask, primary_mask2);
+      alive = path_step_wave<true>(sv, fp, s, alive, primary_mask, primary_mask2 RT_PH_ARGS);
       primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
-      rough_total += s.rough;
-      s.rough = 0;
+      rough_total += s.rough & 0x7fffffffu;
+      s.rough &= 0x80000000u;  // keeps "ended on a miss" (the skybox is sampled in path_end)
       finished |= was & !alive;
     }
     unsigned int *counts = wave_count[iters & 1u];
@@ -605,6 +674,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
     const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
     if (lane == 0) counts[wave] = static_cast<uint32_t>(__popcll(live));
     __syncthreads();
+    RT_PH_MARK(4)
     uint32_t total = 0, before = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -626,7 +696,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
         q[3] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p | (s.seg << 26)));
       }
       if (finished) {  // the lane's registers are about to change hands
-        path_end(fp, s);
+        path_end<true>(fp, s);
         seg_total += s.seg;
         finished = false;
       }
@@ -650,12 +720,15 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
       live_waves = need;
       // No barrier here: the exchange buffer is next written after the next count barrier, which the
       // surviving waves only pass once their reads above have completed.
+      RT_PH_MARK(5)
     }
   }
+  RT_PH_MARK(5)
   if (finished) {
-    path_end(fp, s);
+    path_end<true>(fp, s);
     seg_total += s.seg;
   }
+  RT_PH_MARK(6)
   // totals: one atomic set per wave on the workgroup's shard (waves end at different times here)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -668,15 +741,17 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
     if (rough_total) atomicAdd(&shard[1], static_cast<unsigned long long>(rough_total));
     atomicAdd(&shard[2], static_cast<unsigned long long>(iters));
   }
+  RT_PH_FLUSH(fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride)
 }
 
 // Resident waves + lane refill.  `refill_min`: idle lanes a wave tolerates before it pulls
 // new pixels (1 = refill at once).  fp.tile_counters: 8 counters, 128 B apart, zero at launch.
 __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent(DeviceScene sc, FrameParams fp, uint32_t refill_min,
                                                             uint32_t tile_chunk) {
-  extern __shared__ float4 lds_sph[];
-  for (uint32_t i = threadIdx.x; i < sc.n_sph_pad; i += kBlock) lds_sph[i] = sc.sph[i];
+  extern __shared__ float4 lds_image[];
+  for (uint32_t i = threadIdx.x; i < sc.image_records; i += kBlock) lds_image[i] = sc.image[i];
   __syncthreads();
+  const SceneView sv = make_view(sc, lds_image, lds_image);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
   const uint32_t n_tiles = tiles_x * fp.frame_tile_rows * fp.batch;
@@ -701,6 +776,7 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
   uint32_t tile = 0, tpos = 64;  // wave-uniform cursor into the current tile
   bool work_left = n_tiles != 0u;
   uint32_t seg_total = 0, rough_total = 0, wave_iters = 0;
+  RT_PH_DECL
 
   for (;;) {
     const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
@@ -746,7 +822,7 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
           if ((x < fp.width) & (lrow < fp.local_rows)) {
             path_begin(fp, x, lrow, tp.frame, s);
             alive = fp.reflection_limit != 0u;
-            if (!alive) path_end(fp, s);
+            if (!alive) path_end<true>(fp, s);
           }
         }
         const uint32_t n_need = static_cast<uint32_t>(__popcll(need));
@@ -764,11 +840,11 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
     wave_iters += 1u;
     {
       const bool was = alive;
-      alive = path_step_wave<false>(sc, lds_sph, fp, s, alive);
+      alive = path_step_wave<true>(sv, fp, s, alive, nullptr, nullptr RT_PH_ARGS);
       if (was & !alive) {
-        path_end(fp, s);
+        path_end<true>(fp, s);
         seg_total += s.seg;
-        rough_total += s.rough;
+        rough_total += s.rough & 0x7fffffffu;
       }
     }
   }
@@ -827,7 +903,7 @@ __global__ void __launch_bounds__(256) cull_slabs_kernel(DeviceScene sc, FramePa
     const uint32_t i = w * 64u + lane;
     bool keep = false;
     if (i < sc.n_sph) {
-      const float4 g = sc.sph[i];
+      const float4 g = sc.image[i];
       const f3 rel = mk3(g.x, g.y, g.z) - fp.cam_pos;
       const float dist = length3(rel);
       const float r = sqrtf(fmaxf(g.w, 0.0f)) * 1.001f + 0.002f * dist + 1e-6f;
@@ -942,7 +1018,9 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   const uint64_t tiles = static_cast<uint64_t>(tiles_x) * tiles_y * fp.batch;  // the batch as one stacked image
   if (tiles == 0) return 0;
   if (tiles * (kTile * kTile) > 0xffffffffull) return static_cast<int>(hipErrorInvalidValue);  // pixel indices are 32-bit
-  const size_t lds = static_cast<size_t>(sc.n_sph_pad) * sizeof(float4);
+  const size_t lds_sph = static_cast<size_t>(sc.n_sph_pad) * sizeof(float4);
+  const size_t lds_image = static_cast<size_t>(sc.image_records) * sizeof(float4);
+  const bool image_fits = sc.image_records <= kImageLdsRecords;  // whole scene image in LDS (<= 16 KB)
   int variant = lc.variant;
   if (variant < 0) {
     // Measured on MI355X.  Re-packing a workgroup's surviving paths pays once a frame
@@ -954,8 +1032,10 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   }
   // the packed path state keeps 6 bits of bounce count and 26 bits of pixel index
   if (variant == 3 && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26))) variant = 0;
-  // scenes whose sphere records do not fit a workgroup's default 64 KB of LDS are scanned from global memory
-  if (lds + (variant == 3 ? kXchgPaths * 64u : 0u) > 60u * 1024u) variant = 1;
+  // the re-packing and resident-wave shapes keep the whole scene image in LDS; bigger scenes render as tiles
+  if ((variant == 3 || variant == 2) && !image_fits) variant = 0;
+  // tiles whose sphere records do not fit a workgroup's default 64 KB of LDS scan them from global memory
+  if (variant == 0 && !image_fits && lds_sph > 60u * 1024u) variant = 1;
   if (variant_used) *variant_used = variant;
   if (variant == 2) {
     uint32_t blocks = static_cast<uint32_t>(lc.persistent_blocks);
@@ -963,18 +1043,20 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     if (blocks > max_useful) blocks = static_cast<uint32_t>(max_useful);
     if (blocks == 0) blocks = 1;
     const uint32_t chunk = static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
-    hipLaunchKernelGGL(render_persistent, dim3(blocks), dim3(kBlock), lds, stream, sc, fp,
+    hipLaunchKernelGGL(render_persistent, dim3(blocks), dim3(kBlock), lds_image, stream, sc, fp,
                        static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 3) {
     const uint32_t blocks = static_cast<uint32_t>((tiles + 3) / 4);
-    const size_t bytes = lds + static_cast<size_t>(kXchgPaths) * 4 * sizeof(float4);
+    const size_t bytes = lds_image + static_cast<size_t>(kXchgPaths) * 4 * sizeof(float4);
     hipLaunchKernelGGL(render_blocks<4>, dim3(blocks), dim3(256), bytes, stream, sc, fp);
   } else {
     const uint32_t blocks = static_cast<uint32_t>((tiles + (kBlock / 64) - 1) / (kBlock / 64));
     if (variant == 1) {
-      hipLaunchKernelGGL(render_tiles<false>, dim3(blocks), dim3(kBlock), 0, stream, sc, fp);
+      hipLaunchKernelGGL(render_tiles<0>, dim3(blocks), dim3(kBlock), 0, stream, sc, fp);
+    } else if (image_fits) {
+      hipLaunchKernelGGL(render_tiles<2>, dim3(blocks), dim3(kBlock), lds_image, stream, sc, fp);
     } else {
-      hipLaunchKernelGGL(render_tiles<true>, dim3(blocks), dim3(kBlock), lds, stream, sc, fp);
+      hipLaunchKernelGGL(render_tiles<1>, dim3(blocks), dim3(kBlock), lds_sph, stream, sc, fp);
     }
   }
   return static_cast<int>(hipGetLastError());

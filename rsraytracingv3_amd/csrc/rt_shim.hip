@@ -422,57 +422,56 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
     return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_scene: Config has a zero width or height");
   camera_setup(ctx);
 
-  // Re-lay the AoS wire records out for the kernel (rt_device.h).
+  // Re-lay the AoS wire records out for the kernel: the scene image of rt_device.h.
   const auto *wire = static_cast<const uint8_t *>(objects);
-  std::vector<float4> sph, pl_a, pl_b, mat0(object_count), mat1(object_count);
+  std::vector<float4> sph, smat0, smat1, pl_a, pl_b, pmat0, pmat1;
   std::vector<int> sph_obj;
   for (uint32_t i = 0; i < object_count; ++i) {
     rt_wire_object o;
     std::memcpy(&o, wire + static_cast<size_t>(i) * RT355_OBJECT_STRIDE, sizeof o);
-    if (o.option == 0u) {  // ray.hlsl:53-68
-      sph.push_back(make_float4(o.center[0], o.center[1], o.center[2], o.f32_data * o.f32_data));
-      sph_obj.push_back(static_cast<int>(i));
-    } else if (o.option == 1u) {  // ray.hlsl:69-94
-      pl_a.push_back(make_float4(o.center[0], o.center[1], o.center[2], o.f32_data));
-      pl_b.push_back(make_float4(o.vec_data[0], o.vec_data[1], o.vec_data[2], u2f(i)));
-    }  // any other option never intersects (ray.hlsl:53,69)
     float inv_exp = 0.0f;
     if (o.roughness != 0.0f) {  // random.hlsl:30-33
       const float smoothness = 1.0f - o.roughness;
       const float phong_alpha = pow_spec(1000.0f, smoothness * smoothness);
       inv_exp = 1.0f / (phong_alpha + 1.0f);
     }
-    mat0[i] = make_float4(o.colour[0] * 2.0f, o.colour[1] * 2.0f, o.colour[2] * 2.0f, o.roughness);
-    mat1[i] = make_float4(o.emission[0] * o.emission_strength, o.emission[1] * o.emission_strength,
-                          o.emission[2] * o.emission_strength, inv_exp);
+    const float4 m0 = make_float4(o.colour[0] * 2.0f, o.colour[1] * 2.0f, o.colour[2] * 2.0f, o.roughness);
+    const float4 m1 = make_float4(o.emission[0] * o.emission_strength, o.emission[1] * o.emission_strength,
+                                  o.emission[2] * o.emission_strength, inv_exp);
+    if (o.option == 0u) {  // ray.hlsl:53-68
+      sph.push_back(make_float4(o.center[0], o.center[1], o.center[2], o.f32_data * o.f32_data));
+      sph_obj.push_back(static_cast<int>(i));
+      smat0.push_back(m0);
+      smat1.push_back(m1);
+    } else if (o.option == 1u) {  // ray.hlsl:69-94
+      pl_a.push_back(make_float4(o.center[0], o.center[1], o.center[2], o.f32_data));
+      pl_b.push_back(make_float4(o.vec_data[0], o.vec_data[1], o.vec_data[2], u2f(i)));
+      pmat0.push_back(m0);
+      pmat1.push_back(m1);
+    }  // any other option never intersects (ray.hlsl:53,69)
   }
   const size_t n_sph_live = sph.size(), n_pl = pl_a.size();
   // Pad the sphere records to whole scan batches plus one batch of read-ahead with records no
   // ray can accept (r*r = -inf makes the discriminant -inf), so the scan needs no tail code.
   const size_t n_sph = (n_sph_live + kSphBatch - 1) / kSphBatch * kSphBatch + kSphBatch;
   sph.resize(n_sph, make_float4(0.0f, 0.0f, 0.0f, -INFINITY));
+  smat0.resize(n_sph, make_float4(0, 0, 0, 0));
+  smat1.resize(n_sph, make_float4(0, 0, 0, 0));
   sph_obj.resize(n_sph, -1);
   const size_t sph_obj_rec = (n_sph + 3) / 4;  // ints packed into float4 records
-  const size_t total = n_sph + sph_obj_rec + 2 * n_pl + 2 * static_cast<size_t>(object_count) + 1;
+  const size_t total = 3 * n_sph + 4 * n_pl + sph_obj_rec;
   std::vector<float4> blob(total, make_float4(0, 0, 0, 0));
-  size_t off = 0;
-  const size_t off_sph = off;
-  if (n_sph) std::memcpy(&blob[off], sph.data(), n_sph * 16);
-  off += n_sph;
-  const size_t off_sobj = off;
-  if (n_sph) std::memcpy(&blob[off], sph_obj.data(), n_sph * 4);
-  off += sph_obj_rec;
-  const size_t off_pla = off;
-  if (n_pl) std::memcpy(&blob[off], pl_a.data(), n_pl * 16);
-  off += n_pl;
-  const size_t off_plb = off;
-  if (n_pl) std::memcpy(&blob[off], pl_b.data(), n_pl * 16);
-  off += n_pl;
-  const size_t off_m0 = off;
-  if (object_count) std::memcpy(&blob[off], mat0.data(), static_cast<size_t>(object_count) * 16);
-  off += object_count;
-  const size_t off_m1 = off;
-  if (object_count) std::memcpy(&blob[off], mat1.data(), static_cast<size_t>(object_count) * 16);
+  auto put = [&](size_t at, const void *src, size_t bytes) {
+    if (bytes) std::memcpy(reinterpret_cast<unsigned char *>(blob.data()) + at * 16, src, bytes);
+  };
+  put(0, sph.data(), n_sph * 16);
+  put(n_sph, smat0.data(), n_sph * 16);
+  put(2 * n_sph, smat1.data(), n_sph * 16);
+  put(3 * n_sph, pl_a.data(), n_pl * 16);
+  put(3 * n_sph + n_pl, pl_b.data(), n_pl * 16);
+  put(3 * n_sph + 2 * n_pl, pmat0.data(), n_pl * 16);
+  put(3 * n_sph + 3 * n_pl, pmat1.data(), n_pl * 16);
+  put(3 * n_sph + 4 * n_pl, sph_obj.data(), n_sph * 4);
 
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old scene
   if (ctx->scene_cap < total) {
@@ -483,16 +482,12 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
     ctx->scene_cap = total;
   }
   RT_HIP(ctx, hipMemcpy(ctx->d_scene, blob.data(), total * 16, hipMemcpyHostToDevice));
-  ctx->scene.sph = ctx->d_scene + off_sph;
-  ctx->scene.sph_obj = reinterpret_cast<const int *>(ctx->d_scene + off_sobj);
-  ctx->scene.pl_a = ctx->d_scene + off_pla;
-  ctx->scene.pl_b = ctx->d_scene + off_plb;
-  ctx->scene.mat0 = ctx->d_scene + off_m0;
-  ctx->scene.mat1 = ctx->d_scene + off_m1;
+  ctx->scene.image = ctx->d_scene;
   ctx->scene.n_sph = static_cast<uint32_t>(n_sph_live);
   ctx->scene.n_sph_pad = static_cast<uint32_t>(n_sph);
   ctx->scene.n_pl = static_cast<uint32_t>(n_pl);
   ctx->scene.n_obj = object_count;
+  ctx->scene.image_records = static_cast<uint32_t>(total);
   ctx->have_scene = true;
   ctx->masks_dirty = true;
   ctx->stats.object_count = object_count;
@@ -735,7 +730,7 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   lc.variant = ctx->variant;
   lc.refill_min = ctx->refill_min < 1 ? 1 : (ctx->refill_min > 64 ? 64 : ctx->refill_min);
   int per_cu = ctx->blocks_per_cu;
-  if (per_cu <= 0) per_cu = persistent_blocks_per_cu(static_cast<size_t>(ctx->scene.n_sph_pad) * sizeof(float4));
+  if (per_cu <= 0) per_cu = persistent_blocks_per_cu(static_cast<size_t>(ctx->scene.image_records) * sizeof(float4));
   if (per_cu <= 0) per_cu = 4;
   lc.persistent_blocks = per_cu * ctx->cu_count;
   lc.tile_chunk = ctx->tile_chunk;
@@ -878,6 +873,22 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
   ctx->stats.height = ctx->height;
   ctx->stats.local_rows = ctx->local_rows;
   *out = ctx->stats;
+  return RT_OK;
+}
+
+int rt_get_counter_words(rt_context *ctx, uint64_t *out16) {
+  if (!ctx || !out16) return RT_ERR_INVALID_ARGUMENT;
+  if (!ctx->timing_valid) return fail(ctx, RT_ERR_NOT_READY, "rt_get_counter_words: nothing rendered yet");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - 1) % rt_context::kRing);
+  std::vector<unsigned long long> line(rt_context::kCounterWords);
+  RT_HIP(ctx, hipMemcpy(line.data(), ctx->d_counters + rt_context::kCounterWords * static_cast<size_t>(slot),
+                        line.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (uint32_t w = 0; w < kTotalShardStride; ++w) {
+    out16[w] = 0;
+    for (uint32_t sh = 0; sh < kTotalShards; ++sh) out16[w] += line[sh * kTotalShardStride + w];
+  }
   return RT_OK;
 }
 

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Where the waves of the render kernel spend their cycles: runs the profiling build (make -C
+rsraytracingv3_amd/csrc prof -> librt355_prof.so, s_memtime stamps between the phases of the render kernels)
+on the headline workload and prints each phase's share of the summed wave lifetime.
+
+  RT355_LIB=rsraytracingv3_amd/librt355_prof.so python tools/phase_profile.py [--batch 8] [--variant -1]
+The stamps cost ~10 % themselves; use the shares, not the absolute time."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("RT355_LIB", os.path.join(ROOT, "rsraytracingv3_amd", "librt355_prof.so"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import cases  # noqa: E402
+from rsraytracingv3_amd import Connection, Device, RandomTexture, RenderTarget, synth  # noqa: E402
+from rsraytracingv3_amd import _native as N  # noqa: E402
+
+NAMES = ["primary step (culled scan + shade)", "full sphere scan", "cooperative scan (<= 32 rays)", "finish_hit + shade",
+         "count barrier (wait for the block)", "re-pack (exchange + 2nd barrier)", "path_end of the last paths",
+         "staging + first barrier"]
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--variant", type=int, default=-1)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--spheres", type=int, default=64)
+args = ap.parse_args()
+W, H = args.width, args.height
+scene = cases.headline_scene(8) if args.spheres == 64 else cases.stress_scene(args.spheres, 8)
+dev = Device(0)
+dev.set_outputs(N.RT_OUT_RGBA8)
+dev.set_variant(args.variant)
+target = RenderTarget.new(dev, (W, H))
+rt = RandomTexture(dev)
+rt.write(synth.random_texture(1))
+conn = Connection(scene, dev, synth.procedural_skybox(2048, 1024), rt, max_objects="live")
+conn.update_buffers((W, H), scene, (0.0, 0.0))
+jit = synth.jitter_sequence(42, 4096)
+k = 0
+for _ in range(40):
+    if args.batch == 1:
+        conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
+        conn.frame_data.progressive_count = k
+        conn.draw()
+    else:
+        conn.draw_frames(jit[k:k + args.batch], k)
+    k += args.batch
+dev.sync()
+words = (C.c_uint64 * 16)()
+dev.call("rt_get_counter_words", words)
+st = dev.stats()
+ph = np.array(words[4:12], dtype=np.float64)
+print("variant %d, %d frame(s) per launch, kernel %.3f ms, %d segments, %d wave iterations"
+      % (st.last_variant, args.batch, st.last_kernel_ms, st.last_segments, st.last_wave_iterations))
+for name, v in zip(NAMES, ph):
+    print("  %-42s %6.2f %%   %.3e wave-cycles" % (name, 100.0 * v / ph.sum(), v))
