@@ -33,6 +33,13 @@ namespace {
 #ifndef RT_BLOCKS_WAVES
 #define RT_BLOCKS_WAVES 6
 #endif
+#ifndef RT_X2_PREFETCH
+#define RT_X2_PREFETCH 1  // request the second random() texel during the scan (0: when the hit turns out rough)
+#endif
+#ifndef RT_DEFER_SKY_BLOCKS
+#define RT_DEFER_SKY_BLOCKS 0  // render_blocks / render_persistent: 1 = skybox lookup in path_end, 0 = at the miss (A/B on one
+                               // device: deferring costs these shapes 4 %, it pays only in render_tiles)
+#endif
 constexpr int kBlock = 256;
 constexpr int kTile = 8;  // 8x8 pixels per tile / wave
 #ifndef RT_XCHG_PATHS
@@ -424,7 +431,15 @@ __device__ __forceinline__ bool path_shade(const SceneView &sv, const FrameParam
   const float k = 2.0f * dot3(nrm, s.d);          // reflect(), frag.hlsl:23
   f3 nd = fma3(nrm, -k, s.d);
   if (m0.w != 0.0f) {                             // random.hlsl:26-28
+#if RT_X2_PREFETCH
     nd = hemisphere(s.rng, nd, m1.w, x1, x2, seed1);
+#else
+    {
+      const float seed_a = rng_next_seed(s.rng.seed, x1);
+      const float x2_now = fp.rnd[rng_texel(fp, Rng{seed_a, s.rng.px, s.rng.py})];
+      nd = hemisphere(s.rng, nd, m1.w, x1, x2_now, seed_a);
+    }
+#endif
     s.rough += 1;
   }
   s.d = nd;
@@ -454,11 +469,15 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
   // trips hide under the object scan instead of heading the shading chain one after the other.
   float x1 = 0.0f, x2 = 0.0f, seed1 = 0.0f;
   if (alive) x1 = fp.rnd[rng_texel(fp, s.rng)];
+#if RT_X2_PREFETCH
 #define RT_REQUEST_X2                                          \
   if (alive) {                                                 \
     seed1 = rng_next_seed(s.rng.seed, x1);                     \
     x2 = fp.rnd[rng_texel(fp, Rng{seed1, s.rng.px, s.rng.py})]; \
   }
+#else
+#define RT_REQUEST_X2
+#endif
   if (primary_mask != nullptr) {  // wave-uniform: all live lanes carry primary rays of one tile
     if (alive) {
       const SphereHit sh = scan_spheres_listed(sv.sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
@@ -646,7 +665,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   if ((x < fp.width) & (lrow < fp.local_rows) & (tp.frame < fp.batch)) {
     path_begin(fp, x, lrow, tp.frame, s);
     alive = fp.reflection_limit != 0u;
-    if (!alive) path_end<true>(fp, s);
+    if (!alive) path_end<RT_DEFER_SKY_BLOCKS>(fp, s);
   }
   uint32_t live_waves = NW;
   RT_PH_DECL
@@ -663,7 +682,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   for (;;) {
     {
       const bool was = alive;
-      alive = path_step_wave<true>(sv, fp, s, alive, primary_mask, primary_mask2 RT_PH_ARGS);
+      alive = path_step_wave<RT_DEFER_SKY_BLOCKS>(sv, fp, s, alive, primary_mask, primary_mask2 RT_PH_ARGS);
       primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
       rough_total += s.rough & 0x7fffffffu;
       s.rough &= 0x80000000u;  // keeps "ended on a miss" (the skybox is sampled in path_end)
@@ -696,7 +715,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
         q[3] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p | (s.seg << 26)));
       }
       if (finished) {  // the lane's registers are about to change hands
-        path_end<true>(fp, s);
+        path_end<RT_DEFER_SKY_BLOCKS>(fp, s);
         seg_total += s.seg;
         finished = false;
       }
@@ -725,7 +744,7 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   }
   RT_PH_MARK(5)
   if (finished) {
-    path_end<true>(fp, s);
+    path_end<RT_DEFER_SKY_BLOCKS>(fp, s);
     seg_total += s.seg;
   }
   RT_PH_MARK(6)
@@ -822,7 +841,7 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
           if ((x < fp.width) & (lrow < fp.local_rows)) {
             path_begin(fp, x, lrow, tp.frame, s);
             alive = fp.reflection_limit != 0u;
-            if (!alive) path_end<true>(fp, s);
+            if (!alive) path_end<RT_DEFER_SKY_BLOCKS>(fp, s);
           }
         }
         const uint32_t n_need = static_cast<uint32_t>(__popcll(need));
@@ -840,9 +859,9 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
     wave_iters += 1u;
     {
       const bool was = alive;
-      alive = path_step_wave<true>(sv, fp, s, alive, nullptr, nullptr RT_PH_ARGS);
+      alive = path_step_wave<RT_DEFER_SKY_BLOCKS>(sv, fp, s, alive, nullptr, nullptr RT_PH_ARGS);
       if (was & !alive) {
-        path_end<true>(fp, s);
+        path_end<RT_DEFER_SKY_BLOCKS>(fp, s);
         seg_total += s.seg;
         rough_total += s.rough & 0x7fffffffu;
       }
