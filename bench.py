@@ -226,7 +226,8 @@ def main():
     # ---- extra legs: one frame per launch (reference call pattern); 80 zero-padded slots ------------------
     def leg_summary(leg, frames_per_launch):
         blk = leg["block"]
-        return {"frames_per_launch": frames_per_launch, "steps": args.steps,
+        return {"frames_per_launch": frames_per_launch, "launches_in_flight": 2 if frames_per_launch == 1 and world == 1 else 1,
+                "steps": args.steps,
                 "ms_per_step": round(leg["elapsed"] / args.steps * 1e3, 5),
                 "mrays_per_s": round(leg["total_seg"] / leg["elapsed"] / 1e6, 2),
                 "kernel_mrays_per_s": round(blk["seg"] / (blk["kernel_ms"] * 1e-3) / 1e6, 2) if blk["kernel_ms"] else None,

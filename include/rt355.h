@@ -206,8 +206,14 @@ enum {
   RT_OPT_BLOCKS_PER_CU = 2,/* variant 2: resident workgroups per CU (0 = occupancy query)       */
   RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump */
   RT_OPT_FLAGS = 4,        /* experiment switches (speed only)                                     */
-  RT_OPT_CULL = 5          /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
+  RT_OPT_CULL = 5,         /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
                               scan is re-done in full and disagreements are counted in rt_stats     */
+  RT_OPT_INFLIGHT = 6      /* single-frame launches (rt_render / rt_render_frame) in flight at once: 2 (default)
+                              = frame k + 1 starts rendering on a second internal stream while the last
+                              workgroups of frame k drain — the reference's loop issues one frame per turn
+                              (app.rs:208-254) and one 1080p frame leaves a fifth of the GPU idle during its
+                              ramp-up and tail; the history is still updated strictly in frame order on the
+                              context's stream.  1 = one launch at a time (kernel times do not overlap).     */
 };
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */

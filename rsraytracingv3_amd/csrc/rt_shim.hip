@@ -85,6 +85,18 @@ struct rt_context {
   bool masks_dirty = true;  // scene, size or partition changed since the masks were built
   float *d_samples = nullptr;  // staging of a batch's float samples (rt_render_frames), batch x padded rows x W x 3
   size_t samples_cap = 0;      // in floats
+  // Two single-frame launches in flight (RT_OPT_INFLIGHT = 2): frame k renders its float sample on render
+  // stream k % 2 into pipe_samples[k % 2] while the tail of frame k - 1 drains on the other stream; the main
+  // stream waits for each render in order and folds the sample into the history (resolve), so the history chain
+  // and everything the caller sees stay in frame order.
+  int inflight = 2;
+  hipStream_t render_stream[2] = {nullptr, nullptr};
+  hipEvent_t render_done[2] = {nullptr, nullptr}, resolve_done[2] = {nullptr, nullptr}, prep_done = nullptr;
+  bool resolve_pending[2] = {false, false};  // resolve_done[i] has been recorded since pipe_samples[i] was written
+  bool prep_pending = false;                 // work the renders depend on was queued on the main stream (prep_done)
+  float *d_pipe_samples[2] = {nullptr, nullptr};
+  size_t pipe_cap[2] = {0, 0};  // in floats
+  uint64_t pipe_frames = 0;
   rt_stats stats{};
   std::string error;
 };
@@ -251,6 +263,12 @@ int rt_create(int device_id, rt_context **out_ctx) {
       return bail(RT_ERR_DEVICE);
   for (int i = 0; i < 2; ++i)
     if (hipEventCreateWithFlags(&ctx->rnd_last_use[i], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
+  for (int i = 0; i < 2; ++i)
+    if (hipStreamCreateWithFlags(&ctx->render_stream[i], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->render_done[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->resolve_done[i], hipEventDisableTiming) != hipSuccess)
+      return bail(RT_ERR_DEVICE);
+  if (hipEventCreateWithFlags(&ctx->prep_done, hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
   if (hipMalloc(&ctx->d_counters, rt_context::kRing * rt_context::kCounterWords * sizeof(unsigned long long)) != hipSuccess)
     return bail(RT_ERR_OUT_OF_MEMORY);
   if (hipMemset(ctx->d_counters, 0, rt_context::kRing * rt_context::kCounterWords * sizeof(unsigned long long)) != hipSuccess)
@@ -281,6 +299,14 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_tile_counters);
   (void)hipFree(ctx->d_masks);
   (void)hipFree(ctx->d_samples);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->render_stream[i]) (void)hipStreamSynchronize(ctx->render_stream[i]);
+    (void)hipFree(ctx->d_pipe_samples[i]);
+    if (ctx->render_done[i]) (void)hipEventDestroy(ctx->render_done[i]);
+    if (ctx->resolve_done[i]) (void)hipEventDestroy(ctx->resolve_done[i]);
+    if (ctx->render_stream[i]) (void)hipStreamDestroy(ctx->render_stream[i]);
+  }
+  if (ctx->prep_done) (void)hipEventDestroy(ctx->prep_done);
   (void)hipFree(ctx->d_lut);
   for (int i = 0; i < 2; ++i)
     if (ctx->rnd_last_use[i]) (void)hipEventDestroy(ctx->rnd_last_use[i]);
@@ -557,6 +583,10 @@ int rt_set_option(rt_context *ctx, int option, int value) {
     case RT_OPT_TILE_CHUNK:
       ctx->tile_chunk = value < 1 ? 1 : value;
       return RT_OK;
+    case RT_OPT_INFLIGHT:
+      if (value < 1 || value > 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_INFLIGHT takes 1 or 2");
+      ctx->inflight = value;
+      return RT_OK;
     default:
       return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
   }
@@ -658,18 +688,28 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   // A batch renders float samples of all its frames (each as a frame of its own: count 0, opacity 1)
   // into the staging buffer; resolve_batch_kernel then replays the history update frame by frame.
   ResolveParams rp{};
-  if (batch > 1u) {
+  // Single frames keep two launches in flight (see rt_context::inflight) unless a per-frame diagnostic output
+  // (segments, hits) is on: those buffers describe ONE frame and two kernels must not write them at once.
+  const bool pipelined = batch == 1u && ctx->inflight >= 2 && !(ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS));
+  const int lane = static_cast<int>(ctx->pipe_frames & 1u);
+  hipStream_t render_stream = pipelined ? ctx->render_stream[lane] : ctx->stream;
+  float *staging = nullptr;
+  if (batch > 1u || pipelined) {
     const size_t frame_stride = static_cast<size_t>(fp.frame_tile_rows) * 8u * ctx->width;
     const size_t need = frame_stride * batch * 3u;
-    if (ctx->samples_cap < need) {
-      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      (void)hipFree(ctx->d_samples);
-      ctx->d_samples = nullptr;
-      ctx->samples_cap = 0;
-      RT_HIP(ctx, hipMalloc(&ctx->d_samples, need * sizeof(float)));
-      ctx->samples_cap = need;
+    float **buf = pipelined ? &ctx->d_pipe_samples[lane] : &ctx->d_samples;
+    size_t *cap = pipelined ? &ctx->pipe_cap[lane] : &ctx->samples_cap;
+    if (*cap < need) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the main stream has waited for every render so far
+      (void)hipFree(*buf);
+      *buf = nullptr;
+      *cap = 0;
+      RT_HIP(ctx, hipMalloc(buf, need * sizeof(float)));
+      *cap = need;
+      if (pipelined) ctx->resolve_pending[lane] = false;
     }
-    rp.samples = ctx->d_samples;
+    staging = *buf;
+    rp.samples = staging;
     rp.batch = batch;
     rp.pixels = ctx->local_rows * ctx->width;
     rp.frame_stride = static_cast<uint32_t>(frame_stride);
@@ -688,13 +728,14 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     fp.keep = 0.0f;
     fp.rgba8 = nullptr;
     fp.hist_rgba8 = nullptr;
-    fp.rgbf32 = ctx->d_samples;
+    fp.rgbf32 = staging;
     fp.hist_f32 = nullptr;
     fp.accum_mode = 0;
   }
 
   // Primary-ray culling masks: rebuilt when the scene, the size or the partition changed; valid for
   // every jitter below half a pixel (larger jitters render without culling).
+  bool prep_queued = false;  // something the render kernel reads was queued on the main stream just now
   fp.tile_masks = nullptr;
   fp.mask_words = 0;
   fp.cull_check = 0;
@@ -715,6 +756,7 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
       if (launch_cull_tiles(ctx->scene, fp, ctx->d_masks, ctx->stream) != 0)
         return fail(ctx, RT_ERR_DEVICE, "cull_tiles launch failed");
       ctx->masks_dirty = false;
+      prep_queued = true;
     }
     fp.tile_masks = ctx->d_masks;
     fp.cull_check = ctx->cull == 2;
@@ -724,8 +766,18 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
                                (rt_context::kRing / 2) * rt_context::kTileWords * sizeof(unsigned int), ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(ctx->d_counters + rt_context::kCounterWords * static_cast<size_t>(slot), 0,
                                (rt_context::kRing / 2) * rt_context::kCounterWords * sizeof(unsigned long long), ctx->stream));
+    prep_queued = true;
   }
-  RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], ctx->stream));
+  if (prep_queued) {  // render streams must not start before the masks / re-armed counters are there
+    RT_HIP(ctx, hipEventRecord(ctx->prep_done, ctx->stream));
+    ctx->prep_pending = true;
+  }
+  if (pipelined) {
+    // this lane's sample buffer is free once the resolve that read it (two frames ago) has run
+    if (ctx->resolve_pending[lane]) RT_HIP(ctx, hipStreamWaitEvent(render_stream, ctx->resolve_done[lane], 0));
+    if (ctx->prep_pending) RT_HIP(ctx, hipStreamWaitEvent(render_stream, ctx->prep_done, 0));
+  }
+  RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], render_stream));
   LaunchConfig lc{};
   lc.variant = ctx->variant;
   lc.refill_min = ctx->refill_min < 1 ? 1 : (ctx->refill_min > 64 ? 64 : ctx->refill_min);
@@ -736,14 +788,23 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   lc.tile_chunk = ctx->tile_chunk;
   lc.flags = ctx->flags;
   int variant_used = -1;
-  const int lrc = launch_render(ctx->scene, fp, lc, ctx->stream, &variant_used);
+  const int lrc = launch_render(ctx->scene, fp, lc, render_stream, &variant_used);
   if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
-  RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], ctx->stream));
+  RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], render_stream));
+  if (pipelined) {  // the main stream joins the renders in frame order: everything after this point sees frame k done
+    RT_HIP(ctx, hipEventRecord(ctx->render_done[lane], render_stream));
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->render_done[lane], 0));
+  }
   RT_HIP(ctx, hipEventRecord(ctx->rnd_last_use[rnd], ctx->stream));
   ctx->rnd_used[rnd] = true;
   rnd_lock.unlock();
-  if (batch > 1u && launch_resolve(rp, ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "resolve launch failed");
+  if (staging != nullptr && launch_resolve(rp, ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "resolve launch failed");
   RT_HIP(ctx, hipEventRecord(ctx->ev_resolved[slot], ctx->stream));
+  if (pipelined) {
+    RT_HIP(ctx, hipEventRecord(ctx->resolve_done[lane], ctx->stream));
+    ctx->resolve_pending[lane] = true;
+    ctx->pipe_frames += 1;
+  }
   ctx->stats.last_variant = static_cast<uint32_t>(variant_used);
   if (fp.hits) {
     ctx->hits_valid = true;

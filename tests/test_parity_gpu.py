@@ -9,7 +9,7 @@ import pytest
 
 import cases
 import oracle
-from rsraytracingv3_amd import Connection, RandomTexture, RenderTarget, render_scene
+from rsraytracingv3_amd import Connection, RandomTexture, RenderTarget, render_scene, synth
 from rsraytracingv3_amd import _native as N
 
 pytestmark = pytest.mark.gpu
@@ -402,3 +402,46 @@ def test_batch_launch_limits(device):
     conn.draw_frames([(0.1, 0.1)], 0)  # a batch of one is a plain frame, debug outputs allowed
     device.sync()
     assert target.read_segments().shape == (48, 64)
+
+
+@pytest.mark.parametrize("accum", [N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32])
+def test_two_frames_in_flight_equal_one_at_a_time_and_the_oracle(device, accum):
+    """RT_OPT_INFLIGHT = 2 (default): single-frame launches (the reference's one draw per loop turn,
+    app.rs:208-254) alternate between two internal streams so that frame k + 1 starts while frame k drains; the
+    history is folded in frame order.  12 frames without a sync in between, the random texture replaced on the
+    device every 4 frames: same texels and floats as one launch at a time, and as the oracle's frame chain."""
+    scene = cases.headline_scene(5)
+    size = (200, 120)
+    sky, _ = cases.inputs(256, 128)
+    jit = synth.jitter_sequence(9, 12)
+    results = {}
+    for inflight in (2, 1):
+        device.set_partition(0, 1, 8)
+        device.set_accum_mode(accum)
+        device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
+        device.set_variant(-1)
+        device.set_option(N.RT_OPT_INFLIGHT, inflight)
+        target = RenderTarget.new(device, size)
+        rt = RandomTexture(device, seed=70)
+        rt.generate_on_device()
+        conn = Connection(scene, device, sky, rt, max_objects="live")
+        conn.update_buffers(size, scene, (0.0, 0.0))
+        rt.seed = 70
+        for k in range(12):
+            if k % 4 == 0:
+                rt.generate_on_device()
+            conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
+            conn.frame_data.progressive_count = k
+            conn.draw()
+        device.sync()
+        results[inflight] = (target.read_rgbf32(), target.read_rgba8())
+    device.set_option(N.RT_OPT_INFLIGHT, 2)
+    assert np.array_equal(results[2][0].view(np.uint32), results[1][0].view(np.uint32))
+    assert np.array_equal(results[2][1], results[1][1])
+    hist8 = histf = None
+    for k in range(12):
+        ref = run_oracle(scene, size, sky, synth.random_texture(70 + k // 4), jit[k], max_objects="live", pc=k,
+                         history=hist8, history_f32=histf, accum=1 if accum == N.RT_ACCUM_FLOAT32 else 0)
+        hist8, histf = (None, ref.rgbf32) if accum == N.RT_ACCUM_FLOAT32 else (ref.rgba8, None)
+    assert np.array_equal(results[2][0].view(np.uint32), ref.rgbf32.view(np.uint32))
+    assert np.array_equal(results[2][1], ref.rgba8)
