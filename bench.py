@@ -40,7 +40,13 @@ VALU_PEAK_TFLOPS = 157.3    # FP32 vector peak
 SIMDS = 1024                # 256 CUs x 4
 CLOCK_WARMUP_S = 2.0
 MIN_TIMED_S = 1.0
-KERNEL_NAMES = {0: "render_tiles<true>", 1: "render_tiles<false>", 2: "render_persistent", 3: "render_blocks<4>"}
+KERNEL_NAMES = {0: "render_tiles", 1: "render_tiles<0>", 2: "render_persistent", 3: "render_blocks<4>"}
+
+
+def kernel_name(st):
+    """The render kernel the last launch used, from rt_stats (launch shape + what it staged into LDS)."""
+    v = int(st.last_variant)
+    return "render_tiles<%d>%s" % (st.last_stage, " (sphere grid)" if st.last_stage == 3 else "") if v == 0 else KERNEL_NAMES.get(v, "?")
 
 
 def algorithmic_bytes(pixels, segments, rough):
@@ -221,7 +227,6 @@ def main():
     # ---- headline leg: B frames per launch ------------------------------------------------------------------
     B = args.batch if args.batch > 0 else min(64, 8 * world)
     head = reduce_leg(timed_leg(B, args.steps, args.warmup, args.min_seconds, args.clock_warmup))
-    variant_used = int(head["stats"].last_variant)
 
     # ---- extra legs: one frame per launch (reference call pattern); 80 zero-padded slots ------------------
     def leg_summary(leg, frames_per_launch):
@@ -231,7 +236,7 @@ def main():
                 "ms_per_step": round(leg["elapsed"] / args.steps * 1e3, 5),
                 "mrays_per_s": round(leg["total_seg"] / leg["elapsed"] / 1e6, 2),
                 "kernel_mrays_per_s": round(blk["seg"] / (blk["kernel_ms"] * 1e-3) / 1e6, 2) if blk["kernel_ms"] else None,
-                "kernel": KERNEL_NAMES.get(int(leg["stats"].last_variant), "?"), "blocks_timed": leg["n_blocks"]}
+                "kernel": kernel_name(leg["stats"]), "blocks_timed": leg["n_blocks"]}
 
     single = slots80 = None
     if not args.no_extra_legs:
@@ -320,7 +325,7 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
             "traffic_resolve_kernel": traffic_resolve,
-            "kernel": KERNEL_NAMES.get(variant_used, "?"),
+            "kernel": kernel_name(head["stats"]),
             "avg_launch_ms": round(blk["kernel_ms"] / launches, 5),
             "resolve_avg_launch_ms": round(blk["resolve_ms"] / launches, 5),
             "launches": launches,

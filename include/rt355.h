@@ -72,6 +72,9 @@ typedef struct rt_stats {
                                     full scan in the last frame (must be 0)                    */
   float last_resolve_ms;      /* HIP-event time of the last launch's history-resolve pass (n_frames > 1) */
   uint32_t last_variant;      /* launch shape the last launch used (RT_OPT_VARIANT values 0..3)       */
+  uint32_t last_stage;        /* what that launch staged into LDS: 0 nothing, 1 sphere records, 2 the whole scene
+                                 image, 3 sphere records + the sphere grid (secondary rays walk the grid)   */
+  uint32_t grid_cells, grid_items; /* the current scene's sphere grid (0 = none: small scene, or not buildable) */
 } rt_stats;
 
 /* Device-side view of the context's buffers, for zero-copy consumers (RCCL gather,
@@ -208,12 +211,15 @@ enum {
   RT_OPT_FLAGS = 4,        /* experiment switches (speed only)                                     */
   RT_OPT_CULL = 5,         /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
                               scan is re-done in full and disagreements are counted in rt_stats     */
-  RT_OPT_INFLIGHT = 6      /* single-frame launches (rt_render / rt_render_frame) in flight at once: 2 (default)
+  RT_OPT_INFLIGHT = 6,     /* single-frame launches (rt_render / rt_render_frame) in flight at once: 2 (default)
                               = frame k + 1 starts rendering on a second internal stream while the last
                               workgroups of frame k drain — the reference's loop issues one frame per turn
                               (app.rs:208-254) and one 1080p frame leaves a fifth of the GPU idle during its
                               ramp-up and tail; the history is still updated strictly in frame order on the
                               context's stream.  1 = one launch at a time (kernel times do not overlap).     */
+  RT_OPT_GRID_MIN = 7      /* scenes with at least this many spheres (default 129) get a uniform grid at the next
+                              rt_set_scene: secondary rays then test the spheres of the cells they cross instead of
+                              every sphere (ray.hlsl:97-107 scans linearly; the reference caps scenes at 80)       */
 };
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */

@@ -16,7 +16,7 @@ RT_OK = 0
 RT_ACCUM_SRGB8, RT_ACCUM_FLOAT32 = 0, 1
 RT_OUT_RGBA8, RT_OUT_RGBF32, RT_OUT_SEGMENTS, RT_OUT_HITS = 1, 2, 4, 8
 RT_OPT_VARIANT, RT_OPT_REFILL_MIN, RT_OPT_BLOCKS_PER_CU, RT_OPT_TILE_CHUNK, RT_OPT_FLAGS, RT_OPT_CULL = 0, 1, 2, 3, 4, 5
-RT_OPT_INFLIGHT = 6
+RT_OPT_INFLIGHT, RT_OPT_GRID_MIN = 6, 7
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_NOT_READY",
                 -4: "RT_ERR_DEVICE", -5: "RT_ERR_OUT_OF_MEMORY"}
@@ -34,7 +34,8 @@ class RtStats(C.Structure):
                 ("height", C.c_uint32), ("local_rows", C.c_uint32), ("object_count", C.c_uint32),
                 ("sphere_count", C.c_uint32), ("plane_count", C.c_uint32), ("last_batch", C.c_uint32),
                 ("last_wave_iterations", C.c_uint64), ("last_cull_mismatches", C.c_uint64),
-                ("last_resolve_ms", C.c_float), ("last_variant", C.c_uint32)]
+                ("last_resolve_ms", C.c_float), ("last_variant", C.c_uint32), ("last_stage", C.c_uint32),
+                ("grid_cells", C.c_uint32), ("grid_items", C.c_uint32)]
 
 
 class RtDeviceBuffers(C.Structure):

@@ -32,8 +32,27 @@ constexpr uint32_t kMaxBatch = 64;  // frames one launch can render (rt_render_f
 //   [3n+4p, ...)      sph_obj original object index per sphere slot (ints, 4 per record; -1 in the padding)
 // Materials are indexed by SLOT, so the winner's material needs no object index first (one dependent
 // gather less per shaded hit), and for scenes of up to kImageLdsRecords records the whole image lives in LDS.
+// Uniform grid over the spheres of a large scene (hundreds of spheres; built on the host at rt_set_scene,
+// rt_grid.h).  Secondary rays walk it cell by cell (3-D DDA) and test only the spheres registered in the cells
+// they cross instead of scanning every sphere.  cell_start[n_cells + 1] (u32) and items[] (u16 sphere slots) sit
+// behind the scene image proper, at records off_cells / off_items; kernels stage them into LDS with the sphere
+// records.  A sphere is registered in every cell its INFLATED ball touches, inflated enough that any ray the float
+// test of ray.hlsl:53-68 can accept reaches the cell where the sphere is registered no later than the accepted
+// distance (derivation at scan_grid in rt_kernels.hip) — for rays that start inside [near_min, near_max]; others
+// scan linearly.
+struct GridParams {
+  uint32_t enabled;
+  uint32_t nx, ny, nz, n_cells, n_items;
+  uint32_t off_cells, off_items;  // float4-record offsets into the scene image
+  float gmin[3], gmax[3];         // the grid's box
+  float cell[3], inv_cell[3];     // cell size per axis and its reciprocal
+  float near_min[3], near_max[3];
+  float t_margin;                 // a hit ends the walk when it lies this far before the current cell's exit
+};
+
 struct DeviceScene {
   const float4 *image;
+  GridParams grid;
   uint32_t n_sph, n_pl, n_obj;
   uint32_t n_sph_pad;      // records in sph[]: n_sph rounded up to kSphBatch, plus one batch of read-ahead
   uint32_t image_records;  // float4 records in the whole image
@@ -118,7 +137,8 @@ int persistent_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);
 int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream);
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream,
-                  int *variant_used = nullptr);  // variant_used: the launch shape chosen (0..3)
+                  int *variant_used = nullptr, int *stage_used = nullptr);  // the launch shape chosen (0..3) and what
+                                                                            // it staged into LDS (render_tiles<STAGE>)
 int launch_resolve(const ResolveParams &rp, hipStream_t stream);
 int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned long long *masks, hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);

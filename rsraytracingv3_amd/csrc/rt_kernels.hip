@@ -93,6 +93,20 @@ __device__ __forceinline__ float sqrt_rn(float x) {
 #define RT_PH_ARGS
 #endif
 
+// The same for divergent code (lanes test different spheres): the rare small-input branch is per lane.
+__device__ __forceinline__ float sqrt_rn_lane(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __uint_as_float(__float_as_uint(s) - 1u);
+  const float su = __uint_as_float(__float_as_uint(s) + 1u);
+  const float rd = fmaf(-sd, s, x);
+  const float ru = fmaf(-su, s, x);
+  float r = (rd <= 0.0f) ? sd : s;
+  r = (ru > 0.0f) ? su : r;
+  if ((__float_as_uint(x) - 1u) < (0x0f800000u - 1u)) r = sqrtf(x);
+  return r;
+}
+constexpr uint32_t kGridMaxDimDevice = 64;  // = kGridMaxDim of rt_grid.h
+
 struct Rng {
   float seed, px, py;  // random.hlsl:1-2
 };
@@ -149,6 +163,8 @@ struct SceneView {
   const float4 *sph, *smat0, *smat1, *pl_a, *pl_b, *pmat0, *pmat1;
   const int *sph_obj;
   uint32_t n_sph_pad, n_pl;
+  const uint32_t *grid_cells;  // cell_start[n_cells + 1], or null
+  const uint16_t *grid_items;
 };
 // `sph_base`: record 0 of the sphere array; `rest_base`: record 0 of an image that holds everything else
 // (the two are the same pointer when the whole image was staged).
@@ -164,6 +180,8 @@ __device__ __forceinline__ SceneView make_view(const DeviceScene &sc, const floa
   v.sph_obj = reinterpret_cast<const int *>(rest_base + sc.off_sph_obj());
   v.n_sph_pad = sc.n_sph_pad;
   v.n_pl = sc.n_pl;
+  v.grid_cells = nullptr;
+  v.grid_items = nullptr;
   return v;
 }
 
@@ -334,6 +352,79 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
   return SphereHit{best_key, slot};
 }
 
+// ---- uniform grid walk (large scenes) -----------------------------------------------------------------------
+// The sphere part of ray.hlsl:97-107 for ONE ray per lane, lanes diverge: a 3-D DDA over the grid of rt_grid.h,
+// testing the spheres registered in every crossed cell with the arithmetic of the linear scan, until the best hit
+// lies before the exit of the current cell (minus a margin) or the ray leaves the grid.
+// Same result as the linear scan: (1) the per-sphere arithmetic is the same, so a sphere gives the same key
+// wherever it is tested (a sphere registered in several cells is simply tested again); (2) the winner is the
+// lexicographic minimum of (key, slot) — the linear scan's strict '<' in ascending slot order; (3) every sphere
+// the float test can accept at distance t has the point o + t d inside its registered ball (rt_grid.h), hence in a
+// cell the walk has visited once its cell-exit parameter has passed t; the walk only stops at a hit that is
+// t_margin before the current exit, so no unvisited sphere can have an equal or smaller distance.  The
+// traversal's own arithmetic (approximate reciprocals, accumulated boundary parameters) only moves cell
+// boundaries by far less than the registration slack.  RT_OPT_CULL = 2 re-scans linearly and counts disagreements.
+__device__ __forceinline__ SphereHit scan_grid(const SceneView &sv, const GridParams &gp, f3 o, f3 d) {
+  uint32_t best_key = kNoHitKey;
+  int best_slot = -1;
+  const float big = 1e30f;
+  const float ivx = fabsf(d.x) > 1e-30f ? __builtin_amdgcn_rcpf(d.x) : (d.x < 0.0f ? -big : big);
+  const float ivy = fabsf(d.y) > 1e-30f ? __builtin_amdgcn_rcpf(d.y) : (d.y < 0.0f ? -big : big);
+  const float ivz = fabsf(d.z) > 1e-30f ? __builtin_amdgcn_rcpf(d.z) : (d.z < 0.0f ? -big : big);
+  // ray against the grid's box
+  const float ax = (gp.gmin[0] - o.x) * ivx, bx = (gp.gmax[0] - o.x) * ivx;
+  const float ay = (gp.gmin[1] - o.y) * ivy, by = (gp.gmax[1] - o.y) * ivy;
+  const float az = (gp.gmin[2] - o.z) * ivz, bz = (gp.gmax[2] - o.z) * ivz;
+  const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+  const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+  if (!(t_in <= t_out)) return SphereHit{best_key, best_slot};  // misses the box (or NaN): no sphere can be accepted
+  // the cell of the entry point
+  const f3 p = fma3(d, t_in, o);
+  const int nx = static_cast<int>(gp.nx), ny = static_cast<int>(gp.ny), nz = static_cast<int>(gp.nz);
+  int ix = min(max(static_cast<int>(floorf((p.x - gp.gmin[0]) * gp.inv_cell[0])), 0), nx - 1);
+  int iy = min(max(static_cast<int>(floorf((p.y - gp.gmin[1]) * gp.inv_cell[1])), 0), ny - 1);
+  int iz = min(max(static_cast<int>(floorf((p.z - gp.gmin[2]) * gp.inv_cell[2])), 0), nz - 1);
+  const int sx = d.x >= 0.0f ? 1 : -1, sy = d.y >= 0.0f ? 1 : -1, sz = d.z >= 0.0f ? 1 : -1;
+  // parameter at which the ray leaves the current cell along each axis, and its increment per cell
+  float tx = fmaxf((fmaf(static_cast<float>(ix + (sx > 0 ? 1 : 0)), gp.cell[0], gp.gmin[0]) - o.x) * ivx, t_in);
+  float ty = fmaxf((fmaf(static_cast<float>(iy + (sy > 0 ? 1 : 0)), gp.cell[1], gp.gmin[1]) - o.y) * ivy, t_in);
+  float tz = fmaxf((fmaf(static_cast<float>(iz + (sz > 0 ? 1 : 0)), gp.cell[2], gp.gmin[2]) - o.z) * ivz, t_in);
+  const float dtx = gp.cell[0] * fabsf(ivx), dty = gp.cell[1] * fabsf(ivy), dtz = gp.cell[2] * fabsf(ivz);
+  for (uint32_t guard = 0; guard < 3u * kGridMaxDimDevice + 3u; ++guard) {  // a walk crosses at most nx + ny + nz cells
+    const uint32_t cell = static_cast<uint32_t>((iz * ny + iy) * nx + ix);
+    const uint32_t first = sv.grid_cells[cell], last = sv.grid_cells[cell + 1u];
+    for (uint32_t k = first; k < last; ++k) {
+      const int slot = static_cast<int>(sv.grid_items[k]);
+      const float4 g = sv.sph[slot];
+      const float nxv = o.x - g.x, nyv = o.y - g.y, nzv = o.z - g.z;
+      const float dn = fmaf(d.z, nzv, fmaf(d.y, nyv, d.x * nxv));
+      const float q = fmaf(dn, dn, -(fmaf(nzv, nzv, fmaf(nyv, nyv, nxv * nxv)) - g.w));
+      if (fminf(q, -dn) >= 0.0f) {
+        const uint32_t key = __float_as_uint(-dn - sqrt_rn_lane(q)) - kEpsBits;
+        const bool take = (key < best_key) | ((key == best_key) & (slot < best_slot));
+        best_slot = take ? slot : best_slot;
+        best_key = take ? key : best_key;
+      }
+    }
+    const float t_exit = fminf(tx, fminf(ty, tz));
+    if (best_key != kNoHitKey && __uint_as_float(best_key + kEpsBits) < t_exit - gp.t_margin) break;
+    if (tx <= ty && tx <= tz) {
+      ix += sx;
+      tx += dtx;
+      if (ix < 0 || ix >= nx) break;
+    } else if (ty <= tz) {
+      iy += sy;
+      ty += dty;
+      if (iy < 0 || iy >= ny) break;
+    } else {
+      iz += sz;
+      tz += dtz;
+      if (iz < 0 || iz >= nz) break;
+    }
+  }
+  return SphereHit{best_key, best_slot};
+}
+
 // The rest of ray.hlsl:97-107: sphere result -> Hit, then the planes (ray.hlsl:69-94).
 __device__ __forceinline__ Hit finish_hit(const SceneView &sv, SphereHit sh, f3 o, f3 d) {
   const float best = __uint_as_float(sh.key + kEpsBits);
@@ -457,10 +548,11 @@ __device__ __forceinline__ bool path_shade(const SceneView &sv, const FrameParam
 // lane carries a ray).  The first random() texel is requested before the scan and used after it if the hit is
 // rough: the gather's latency (an L2 round trip) hides under the object scan.  Picks the
 // wave-cooperative scan when at most 32 lanes are live.  Returns the lane's new `alive`.
-template <bool DEFER_SKY>
+template <bool DEFER_SKY, bool GRID = false>
 __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameParams &fp, Path &s, bool alive,
                                                const unsigned long long *__restrict__ primary_mask,
-                                               const unsigned long long *__restrict__ primary_mask2 RT_PH_PARAMS) {
+                                               const unsigned long long *__restrict__ primary_mask2 RT_PH_PARAMS,
+                                               const GridParams *gp = nullptr) {
   const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
   const uint32_t n_live = static_cast<uint32_t>(__popcll(live));
   if (n_live == 0u) return false;
@@ -489,6 +581,23 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
       alive = path_shade<DEFER_SKY>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     }
     RT_PH_MARK(0)
+  } else if (GRID) {
+    // large scene: every lane walks the sphere grid for its own ray; rays that start outside the box the grid's
+    // registration radii were derived for, or whose direction is not a unit vector (rt_grid.h), scan linearly
+    SphereHit sh{kNoHitKey, -1};
+    const bool near = alive & (s.o.x >= gp->near_min[0]) & (s.o.x <= gp->near_max[0]) & (s.o.y >= gp->near_min[1]) &
+                      (s.o.y <= gp->near_max[1]) & (s.o.z >= gp->near_min[2]) & (s.o.z <= gp->near_max[2]) &
+                      (fabsf(dot3(s.d, s.d) - 1.0f) <= 4e-6f);  // unit direction (not after a non-unit plane normal)
+    if (near) sh = scan_grid(sv, *gp, s.o, s.d);
+    if (alive & !near) sh = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
+    if (fp.cull_check && near) {  // self-check frame: the linear scan must agree
+      const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
+      if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
+    }
+    RT_PH_MARK(1)
+    RT_REQUEST_X2
+    if (alive) alive = path_shade<DEFER_SKY>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+    RT_PH_MARK(3)
   } else if (n_live <= 32u) {
     const SphereHit sh = scan_spheres_coop(sv.sph, sv.n_sph_pad, s.o, s.d, alive, live, n_live);
     RT_PH_MARK(2)
@@ -585,16 +694,25 @@ __device__ __forceinline__ TilePos tile_pos(const FrameParams &fp, uint32_t tile
 }
 
 // STAGE: 2 = the whole scene image staged into LDS, 1 = only the sphere records (scenes of hundreds of
-// spheres), 0 = nothing (scenes beyond a workgroup's LDS): everything else is read from global memory.
+// spheres), 3 = the sphere records and the sphere grid (secondary rays walk the grid), 0 = nothing (scenes
+// beyond a workgroup's LDS): everything else is read from global memory.
 template <int STAGE>
 __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_image[];
   if (STAGE != 0) {
     const uint32_t n = STAGE == 2 ? sc.image_records : sc.n_sph_pad;
     for (uint32_t i = threadIdx.x; i < n; i += kBlock) lds_image[i] = sc.image[i];
+    if (STAGE == 3) {  // the grid's cell table and item list, straight behind the sphere records
+      const uint32_t m = (sc.grid.off_items - sc.grid.off_cells) + (sc.grid.n_items * 2u + 15u) / 16u;  // records
+      for (uint32_t i = threadIdx.x; i < m; i += kBlock) lds_image[sc.n_sph_pad + i] = sc.image[sc.grid.off_cells + i];
+    }
     __syncthreads();
   }
-  const SceneView sv = make_view(sc, STAGE != 0 ? lds_image : sc.image, STAGE == 2 ? lds_image : sc.image);
+  SceneView sv = make_view(sc, STAGE != 0 ? lds_image : sc.image, STAGE == 2 ? lds_image : sc.image);
+  if (STAGE == 3) {
+    sv.grid_cells = reinterpret_cast<const uint32_t *>(lds_image + sc.n_sph_pad);
+    sv.grid_items = reinterpret_cast<const uint16_t *>(lds_image + sc.n_sph_pad + (sc.grid.off_items - sc.grid.off_cells));
+  }
   RT_PH_DECL
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -616,9 +734,11 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
     alive = fp.reflection_limit != 0u;
   }
   if (fp.tile_masks != nullptr && __builtin_amdgcn_ballot_w64(alive) != 0ull)
-    alive = path_step_wave<true>(sv, fp, s, alive, fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words,
-                                 fp.tile_masks + static_cast<size_t>(tiles_x + tp.row) * fp.mask_words RT_PH_ARGS);
-  while (__builtin_amdgcn_ballot_w64(alive) != 0ull) alive = path_step_wave<true>(sv, fp, s, alive, nullptr, nullptr RT_PH_ARGS);
+    alive = path_step_wave<true, STAGE == 3>(sv, fp, s, alive, fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words,
+                                             fp.tile_masks + static_cast<size_t>(tiles_x + tp.row) * fp.mask_words RT_PH_ARGS,
+                                             &sc.grid);
+  while (__builtin_amdgcn_ballot_w64(alive) != 0ull)
+    alive = path_step_wave<true, STAGE == 3>(sv, fp, s, alive, nullptr, nullptr RT_PH_ARGS, &sc.grid);
   if (valid) {
     path_end<true>(fp, s);
     seg = s.seg;
@@ -1030,7 +1150,8 @@ __global__ void sqrt_exhaustive_kernel(unsigned long long *mismatches) {
 
 }  // namespace
 
-int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream, int *variant_used) {
+int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream, int *variant_used,
+                  int *stage_used) {
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
   const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
   if (fp.batch < 1u || fp.batch > kMaxBatch || fp.frame_tile_rows != tiles_y) return static_cast<int>(hipErrorInvalidValue);
@@ -1047,7 +1168,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     // little; scenes with hundreds of spheres and small frames (a rank's share of a tile-split frame)
     // are fastest as plain tiles.  The resident-wave shape (2) is never the fastest since the
     // primary-ray culling, which it cannot use; it stays selectable.
-    variant = (sc.n_sph_pad > 128u || tiles < 24000ull) ? 0 : 3;
+    variant = (sc.n_sph_pad > 128u || tiles < 24000ull || sc.grid.enabled) ? 0 : 3;
   }
   // the packed path state keeps 6 bits of bounce count and 26 bits of pixel index
   if (variant == 3 && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26))) variant = 0;
@@ -1056,6 +1177,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   // tiles whose sphere records do not fit a workgroup's default 64 KB of LDS scan them from global memory
   if (variant == 0 && !image_fits && lds_sph > 60u * 1024u) variant = 1;
   if (variant_used) *variant_used = variant;
+  if (stage_used) *stage_used = 2;  // the re-packing and resident-wave shapes stage the whole image
   if (variant == 2) {
     uint32_t blocks = static_cast<uint32_t>(lc.persistent_blocks);
     const uint64_t max_useful = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
@@ -1070,8 +1192,13 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     hipLaunchKernelGGL(render_blocks<4>, dim3(blocks), dim3(256), bytes, stream, sc, fp);
   } else {
     const uint32_t blocks = static_cast<uint32_t>((tiles + (kBlock / 64) - 1) / (kBlock / 64));
+    if (stage_used) *stage_used = variant == 1 ? 0 : ((sc.grid.enabled && !(lc.flags & 2)) ? 3 : (image_fits ? 2 : 1));
     if (variant == 1) {
       hipLaunchKernelGGL(render_tiles<0>, dim3(blocks), dim3(kBlock), 0, stream, sc, fp);
+    } else if (sc.grid.enabled && !(lc.flags & 2)) {  // RT_OPT_FLAGS bit 1: ignore the grid (A/B)
+      const size_t bytes = lds_sph + (static_cast<size_t>(sc.grid.off_items - sc.grid.off_cells) +
+                                      (static_cast<size_t>(sc.grid.n_items) * 2 + 15) / 16) * sizeof(float4);
+      hipLaunchKernelGGL(render_tiles<3>, dim3(blocks), dim3(kBlock), bytes, stream, sc, fp);
     } else if (image_fits) {
       hipLaunchKernelGGL(render_tiles<2>, dim3(blocks), dim3(kBlock), lds_image, stream, sc, fp);
     } else {

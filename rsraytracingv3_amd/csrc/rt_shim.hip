@@ -17,6 +17,7 @@
 
 #include "../../include/rt355.h"
 #include "rt_device.h"
+#include "rt_grid.h"
 
 using namespace rt355;
 
@@ -90,6 +91,7 @@ struct rt_context {
   // stream waits for each render in order and folds the sample into the history (resolve), so the history chain
   // and everything the caller sees stay in frame order.
   int inflight = 2;
+  int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid
   hipStream_t render_stream[2] = {nullptr, nullptr};
   hipEvent_t render_done[2] = {nullptr, nullptr}, resolve_done[2] = {nullptr, nullptr}, prep_done = nullptr;
   bool resolve_pending[2] = {false, false};  // resolve_done[i] has been recorded since pipe_samples[i] was written
@@ -485,7 +487,12 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   smat1.resize(n_sph, make_float4(0, 0, 0, 0));
   sph_obj.resize(n_sph, -1);
   const size_t sph_obj_rec = (n_sph + 3) / 4;  // ints packed into float4 records
-  const size_t total = 3 * n_sph + 4 * n_pl + sph_obj_rec;
+  const size_t image_records = 3 * n_sph + 4 * n_pl + sph_obj_rec;
+  // large scenes: uniform grid over the spheres, appended behind the image proper
+  GridBuild grid = build_grid(sph, n_sph_live, n_sph, static_cast<uint32_t>(ctx->grid_min_spheres));
+  const size_t cells_rec = grid.params.enabled ? (grid.cell_start.size() * 4 + 15) / 16 : 0;
+  const size_t items_rec = grid.params.enabled ? (grid.items.size() * 2 + 15) / 16 : 0;
+  const size_t total = image_records + cells_rec + items_rec;
   std::vector<float4> blob(total, make_float4(0, 0, 0, 0));
   auto put = [&](size_t at, const void *src, size_t bytes) {
     if (bytes) std::memcpy(reinterpret_cast<unsigned char *>(blob.data()) + at * 16, src, bytes);
@@ -498,6 +505,12 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   put(3 * n_sph + 2 * n_pl, pmat0.data(), n_pl * 16);
   put(3 * n_sph + 3 * n_pl, pmat1.data(), n_pl * 16);
   put(3 * n_sph + 4 * n_pl, sph_obj.data(), n_sph * 4);
+  if (grid.params.enabled) {
+    grid.params.off_cells = static_cast<uint32_t>(image_records);
+    grid.params.off_items = static_cast<uint32_t>(image_records + cells_rec);
+    put(grid.params.off_cells, grid.cell_start.data(), grid.cell_start.size() * 4);
+    put(grid.params.off_items, grid.items.data(), grid.items.size() * 2);
+  }
 
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old scene
   if (ctx->scene_cap < total) {
@@ -513,7 +526,8 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   ctx->scene.n_sph_pad = static_cast<uint32_t>(n_sph);
   ctx->scene.n_pl = static_cast<uint32_t>(n_pl);
   ctx->scene.n_obj = object_count;
-  ctx->scene.image_records = static_cast<uint32_t>(total);
+  ctx->scene.image_records = static_cast<uint32_t>(image_records);
+  ctx->scene.grid = grid.params;
   ctx->have_scene = true;
   ctx->masks_dirty = true;
   ctx->stats.object_count = object_count;
@@ -582,6 +596,9 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       return RT_OK;
     case RT_OPT_TILE_CHUNK:
       ctx->tile_chunk = value < 1 ? 1 : value;
+      return RT_OK;
+    case RT_OPT_GRID_MIN:
+      ctx->grid_min_spheres = value < 1 ? 1 : value;
       return RT_OK;
     case RT_OPT_INFLIGHT:
       if (value < 1 || value > 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_INFLIGHT takes 1 or 2");
@@ -787,8 +804,8 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   lc.persistent_blocks = per_cu * ctx->cu_count;
   lc.tile_chunk = ctx->tile_chunk;
   lc.flags = ctx->flags;
-  int variant_used = -1;
-  const int lrc = launch_render(ctx->scene, fp, lc, render_stream, &variant_used);
+  int variant_used = -1, stage_used = -1;
+  const int lrc = launch_render(ctx->scene, fp, lc, render_stream, &variant_used, &stage_used);
   if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
   RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], render_stream));
   if (pipelined) {  // the main stream joins the renders in frame order: everything after this point sees frame k done
@@ -806,6 +823,9 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     ctx->pipe_frames += 1;
   }
   ctx->stats.last_variant = static_cast<uint32_t>(variant_used);
+  ctx->stats.last_stage = static_cast<uint32_t>(stage_used);
+  ctx->stats.grid_cells = ctx->scene.grid.enabled ? ctx->scene.grid.n_cells : 0u;
+  ctx->stats.grid_items = ctx->scene.grid.enabled ? ctx->scene.grid.n_items : 0u;
   if (fp.hits) {
     ctx->hits_valid = true;
     ctx->hits_rendered_limit = fp.reflection_limit;
