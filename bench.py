@@ -132,8 +132,10 @@ def main():
 
     tiles = None
     if world > 1:
-        from rsraytracingv3_amd.distributed import TileParallelRenderer
-        tiles = TileParallelRenderer(dev, W, H, args.strip_rows)
+        from rsraytracingv3_amd.distributed import TileParallelRenderer, TorchTileRenderer
+        # production: the gather inside librt355 over RCCL; a gloo rehearsal (ranks sharing one GPU, which RCCL
+        # refuses) gathers through torch.distributed and host memory instead
+        tiles = (TileParallelRenderer if args.backend == "nccl" else TorchTileRenderer)(dev, W, H, args.strip_rows)
 
     def run_frames(first, count, B):
         """frames first .. first+count-1 of the accumulation, B per launch; returns the number of launches"""
@@ -297,15 +299,18 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 5),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "strong",  # the frame size is fixed; every GPU renders 1/N of each frame's rows
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
             "workload": "%dx%d, %d spheres + ground plane (%d object slots), %d bounces, 1 spp, %dx%d RGBA32F skybox"
                         % (W, H, args.spheres, n_objects, args.bounces, args.sky, args.sky // 2),
-            "partition": "row strips of %d, round-robin over %d GPU(s)%s" % (args.strip_rows, world,
-                                                                          ", RCCL gather to rank 0" if world > 1 else ""),
+            "partition": "row strips of %d, round-robin over %d GPU(s)%s" % (
+                args.strip_rows, world, ", RCCL gather to rank 0 inside librt355 (rt_comm_init: grouped ncclSend/ncclRecv on "
+                "a communication stream, beside the next launch)" if world > 1 else ""),
+            "headline_mode": "%d consecutive frames of the accumulation per launch (8 per GPU), one gather per launch; the "
+                             "one_frame_per_launch leg is the per-frame figure (one launch and one gather per frame)" % B,
             "kernel_variant": args.variant,
             "frames_per_launch": B,
             "progressive_count": "frame index k (1-spp frames of a resting camera accumulate, app.rs:208-254)",

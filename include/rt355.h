@@ -143,6 +143,36 @@ RT355_API int rt_resize(rt_context *ctx, uint32_t width, uint32_t height);
  * (local row order = ascending global row).  rank 0 / world 1 = the whole frame. */
 RT355_API int rt_set_partition(rt_context *ctx, uint32_t rank, uint32_t world, uint32_t strip_rows);
 
+/* The multi-GPU frame behind the C-ABI: "the frame tile-partitions across the GPUs of one node with an RCCL gather
+ * over xGMI to assemble the image".  The reference has one process, one adapter and one loop (src/app.rs:64-104,
+ * 208-254); here one process drives one GPU, and the N processes of a node form a communicator:
+ *   rank 0:      rt_comm_get_unique_id(id)      128 opaque bytes, handed to the other ranks by the host (any channel)
+ *   every rank:  rt_comm_init(ctx, id, rank, world, strip_rows)   collective; also sets the partition
+ *                (rt_set_partition) — rank r renders the row strips s with s % world == r
+ *   every rank:  the same rt_set_scene / rt_set_skybox / rt_set_random / rt_resize / rt_render* sequence.  After
+ *                each launch the rank's strips travel to rank 0 (grouped ncclSend / ncclRecv, each peer on its own
+ *                xGMI link; no ring, no all-gather) on a communication stream of the context, beside the next
+ *                launch; targets alternate between two buffers so the gather never meets the next launch's writes.
+ *   rank 0:      rt_read_frame_rgba8 returns the assembled height x width frame (after the last gather).
+ * RCCL is bound at run time (dlopen: $RT355_RCCL_LIB, an RCCL already loaded in the process, librccl.so.1), so a
+ * single-GPU host needs none; rt_comm_init returns RT_ERR_NOT_READY when no RCCL can be loaded.  Per-pixel
+ * results do not depend on the partition (the RNG state is per pixel, random.hlsl:1-2,45-47): the assembled frame
+ * is bit-identical to the single-GPU frame. */
+#define RT355_COMM_ID_BYTES 128
+RT355_API int rt_comm_get_unique_id(void *id128);
+RT355_API int rt_comm_init(rt_context *ctx, const void *id128, uint32_t rank, uint32_t world, uint32_t strip_rows);
+RT355_API int rt_comm_destroy(rt_context *ctx);
+/* The whole frame, sRGB8 texels, height x width x 4 bytes: on one GPU the same as rt_read_rgba8; with a
+ * communicator only on rank 0 (other ranks: RT_ERR_INVALID_ARGUMENT; their rt_read_rgba8 still returns their rows). */
+RT355_API int rt_read_frame_rgba8(rt_context *ctx, void *dst, size_t bytes);
+
+/* Rank 0's assembly step on its own, for hosts that move the strips by another transport (and for testing the
+ * layout without a second GPU): rank0_rows = rank 0's local rows, peer_rows = the local rows of ranks 1 .. world-1
+ * concatenated in rank order (exactly what rank 0 receives), all host pointers to sRGB8 texels; frame gets the
+ * height x width image.  Same layout function and kernel as the gather of rt_comm_init. */
+RT355_API int rt_assemble_strips(rt_context *ctx, uint32_t width, uint32_t height, uint32_t world, uint32_t strip_rows,
+                                 const void *rank0_rows, const void *peer_rows, void *frame);
+
 RT355_API int rt_set_accum_mode(rt_context *ctx, int mode);
 RT355_API int rt_set_outputs(rt_context *ctx, uint32_t out_flags);
 

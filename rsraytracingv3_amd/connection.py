@@ -92,6 +92,32 @@ class Device:
         self.call("rt_get_stats", C.byref(st))
         return st
 
+    # -- multi-GPU frame (one process per GPU; the gather runs inside the library over RCCL) ---------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the 128 opaque bytes every rank passes to ``comm_init`` (hand them over by any channel)."""
+        lib = N.load()
+        buf = C.create_string_buffer(128)
+        rc = lib.rt_comm_get_unique_id(buf)
+        if rc != N.RT_OK:
+            raise N.RtError(rc, "rt_comm_get_unique_id", "no RCCL library could be loaded")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int, strip_rows: int = 8):
+        """Collective over all ranks: joins the communicator and takes the row-strip partition."""
+        if len(unique_id) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        self.call("rt_comm_init", C.c_char_p(unique_id), rank, world, strip_rows)
+
+    def comm_destroy(self):
+        self.call("rt_comm_destroy")
+
+    def read_frame_rgba8(self, width: int, height: int) -> np.ndarray:
+        """The assembled frame (rank 0 of a communicator, or the only GPU)."""
+        out = np.empty((height, width, 4), np.uint8)
+        self.call("rt_read_frame_rgba8", out.ctypes.data_as(C.c_void_p), out.nbytes)
+        return out
+
     def device_buffers(self) -> N.RtDeviceBuffers:
         b = N.RtDeviceBuffers()
         self.call("rt_get_device_buffers", C.byref(b))

@@ -140,6 +140,16 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
                   int *variant_used = nullptr, int *stage_used = nullptr);  // the launch shape chosen (0..3) and what
                                                                             // it staged into LDS (render_tiles<STAGE>)
 int launch_resolve(const ResolveParams &rp, hipStream_t stream);
+// rank 0 of a multi-GPU frame: interleave the row strips of all ranks (own buffer + the peers' buffers received
+// into `stack`, rank r's rows at texel offset stack_offset[r]) into the height x width frame
+constexpr uint32_t kMaxRanks = 64;
+struct AssembleParams {
+  uint32_t *frame;
+  const uint32_t *own, *stack;
+  uint32_t width, height, world, strip_rows;
+  uint32_t stack_offset[kMaxRanks];  // in texels; [0] unused
+};
+int launch_assemble(const AssembleParams &ap, hipStream_t stream);
 int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned long long *masks, hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);
 int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream);

@@ -1100,6 +1100,18 @@ __global__ void __launch_bounds__(256) resolve_batch_kernel(ResolveParams rp) {
   }
 }
 
+// Rank 0 of a tile-split frame: frame row y belongs to strip y / strip_rows, dealt round-robin over the ranks
+// (rt_set_partition); rank r keeps its strips as consecutive local rows.
+__global__ void __launch_bounds__(256) assemble_strips_kernel(AssembleParams ap) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= ap.width * ap.height) return;
+  const uint32_t y = i / ap.width, x = i - y * ap.width;
+  const uint32_t strip = y / ap.strip_rows, r = strip % ap.world;
+  const uint32_t local_row = (strip / ap.world) * ap.strip_rows + (y - strip * ap.strip_rows);
+  const size_t src = static_cast<size_t>(local_row) * ap.width + x;
+  ap.frame[i] = r == 0u ? ap.own[src] : ap.stack[ap.stack_offset[r] + src];
+}
+
 // Device-side refill of the random texture: the reference regenerates 600x600
 // uniform floats on a host thread every 4 ms and uploads them (random_texture.rs:56-75, ~360 MB/s of
 // PCIe); here texel k (row-major) is SplitMix64 output k+1 of `seed`, top 24 bits -> [0,1) on the
@@ -1211,6 +1223,13 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
 int launch_resolve(const ResolveParams &rp, hipStream_t stream) {
   if (rp.pixels == 0 || rp.batch == 0) return 0;
   hipLaunchKernelGGL(resolve_batch_kernel, dim3((rp.pixels + 255u) / 256u), dim3(256), 0, stream, rp);
+  return static_cast<int>(hipGetLastError());
+}
+
+int launch_assemble(const AssembleParams &ap, hipStream_t stream) {
+  const uint64_t n = static_cast<uint64_t>(ap.width) * ap.height;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(assemble_strips_kernel, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, stream, ap);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -17,6 +17,7 @@
 
 #include "../../include/rt355.h"
 #include "rt_device.h"
+#include "rt_comm.h"
 #include "rt_grid.h"
 
 using namespace rt355;
@@ -90,6 +91,19 @@ struct rt_context {
   // stream k % 2 into pipe_samples[k % 2] while the tail of frame k - 1 drains on the other stream; the main
   // stream waits for each render in order and folds the sample into the history (resolve), so the history chain
   // and everything the caller sees stay in frame order.
+  // Multi-GPU frame (rt_comm_init): this context is rank comm_rank of comm_world; after every launch its strips
+  // go to rank 0 over RCCL on comm_stream, beside the next launch.  Launch k renders into send[k & 1] with
+  // send[(k & 1) ^ 1] as its history, so the gather of launch k reads a buffer launch k + 1 does not write.
+  ncclComm_t comm = nullptr;
+  uint32_t comm_rank = 0, comm_world = 0;
+  hipStream_t comm_stream = nullptr;
+  uint32_t *d_rgba8_alt = nullptr;  // send[1]; send[0] is d_rgba8
+  hipEvent_t frame_ready[2] = {nullptr, nullptr}, gather_done[2] = {nullptr, nullptr};
+  bool gather_pending[2] = {false, false};
+  uint32_t *d_stack = nullptr, *d_frame = nullptr;  // rank 0: peers' strips as received; the assembled frame
+  std::vector<uint32_t> rank_rows;                  // local rows of every rank
+  uint64_t comm_launches = 0;
+  int last_send = 0;  // send buffer the last launch wrote
   int inflight = 2;
   int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid
   hipStream_t render_stream[2] = {nullptr, nullptr};
@@ -133,12 +147,34 @@ uint32_t count_local_rows(uint32_t height, uint32_t rank, uint32_t world, uint32
   return rows;
 }
 
+// Where rank r's rows sit in the concatenation of the peers' strips (ranks 1 .. world-1, each rank's local rows
+// in order): the layout rank 0 receives into and assemble_strips_kernel reads.  Returns the peers' texel total.
+size_t fill_assemble_layout(AssembleParams &ap, uint32_t width, uint32_t height, uint32_t world, uint32_t strip_rows) {
+  ap.width = width;
+  ap.height = height;
+  ap.world = world;
+  ap.strip_rows = strip_rows;
+  size_t off = 0;
+  for (uint32_t r = 1; r < world; ++r) {
+    ap.stack_offset[r] = static_cast<uint32_t>(off);
+    off += static_cast<size_t>(count_local_rows(height, r, world, strip_rows)) * width;
+  }
+  return off;
+}
+
 void free_target(rt_context *ctx) {
   (void)hipFree(ctx->d_rgba8);
   (void)hipFree(ctx->d_rgbf32);
   (void)hipFree(ctx->d_hist_f32);
   (void)hipFree(ctx->d_segments);
   (void)hipFree(ctx->d_hits);
+  (void)hipFree(ctx->d_rgba8_alt);
+  (void)hipFree(ctx->d_stack);
+  (void)hipFree(ctx->d_frame);
+  ctx->d_rgba8_alt = nullptr;
+  ctx->d_stack = nullptr;
+  ctx->d_frame = nullptr;
+  ctx->gather_pending[0] = ctx->gather_pending[1] = false;
   ctx->d_rgba8 = nullptr;
   ctx->d_rgbf32 = nullptr;
   ctx->d_hist_f32 = nullptr;
@@ -158,11 +194,27 @@ int alloc_target_buffers(rt_context *ctx, size_t px) {
     RT_HIP(ctx, hipMemsetAsync(ctx->d_hist_f32, 0, px * 12, ctx->stream));
   }
   if (ctx->out_flags & RT_OUT_SEGMENTS) RT_HIP(ctx, hipMalloc(&ctx->d_segments, px * 4));
+  if (ctx->comm) {
+    RT_HIP(ctx, hipMalloc(&ctx->d_rgba8_alt, px * 4));
+    RT_HIP(ctx, hipMemsetAsync(ctx->d_rgba8_alt, 0, px * 4, ctx->stream));
+    ctx->rank_rows.assign(ctx->comm_world, 0);
+    size_t peer_px = 0;
+    for (uint32_t r = 0; r < ctx->comm_world; ++r) {
+      ctx->rank_rows[r] = count_local_rows(ctx->height, r, ctx->comm_world, ctx->strip_rows);
+      if (r) peer_px += static_cast<size_t>(ctx->rank_rows[r]) * ctx->width;
+    }
+    if (ctx->comm_rank == 0) {
+      if (peer_px) RT_HIP(ctx, hipMalloc(&ctx->d_stack, peer_px * 4));
+      RT_HIP(ctx, hipMalloc(&ctx->d_frame, static_cast<size_t>(ctx->width) * ctx->height * 4));
+      RT_HIP(ctx, hipMemsetAsync(ctx->d_frame, 0, static_cast<size_t>(ctx->width) * ctx->height * 4, ctx->stream));
+    }
+  }
   return RT_OK;
 }
 
 int alloc_target(rt_context *ctx) {
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream) RT_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
   free_target(ctx);
   ctx->local_rows = count_local_rows(ctx->height, ctx->rank, ctx->world, ctx->strip_rows);
   ctx->masks_dirty = true;
@@ -292,6 +344,18 @@ int rt_destroy(rt_context *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);  // also when the caller bound the null stream (rt_set_stream)
   if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
+  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+  if (ctx->comm) {
+    std::string why;
+    const RcclApi &api = rccl_api(&why);
+    if (api.ok()) (void)api.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->frame_ready[i]) (void)hipEventDestroy(ctx->frame_ready[i]);
+    if (ctx->gather_done[i]) (void)hipEventDestroy(ctx->gather_done[i]);
+  }
+  if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
   free_target(ctx);
   (void)hipFree(ctx->d_hdri);
   (void)hipFree(ctx->d_rnd[0]);
@@ -552,11 +616,124 @@ int rt_set_partition(rt_context *ctx, uint32_t rank, uint32_t world, uint32_t st
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!world || rank >= world || !strip_rows)
     return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_partition: rank %u / world %u / strip %u", rank, world, strip_rows);
+  if (ctx->comm) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_partition: the partition belongs to the communicator (rt_comm_init)");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   ctx->rank = rank;
   ctx->world = world;
   ctx->strip_rows = strip_rows;
   return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
+}
+
+int rt_comm_get_unique_id(void *id128) {
+  if (!id128) return RT_ERR_INVALID_ARGUMENT;
+  std::string why;
+  const RcclApi &api = rccl_api(&why);
+  if (!api.ok()) return RT_ERR_NOT_READY;
+  ncclUniqueId id;
+  if (api.GetUniqueId(&id) != ncclSuccess) return RT_ERR_DEVICE;
+  static_assert(sizeof id == RT355_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+  std::memcpy(id128, &id, sizeof id);
+  return RT_OK;
+}
+
+int rt_comm_init(rt_context *ctx, const void *id128, uint32_t rank, uint32_t world, uint32_t strip_rows) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!id128 || !world || rank >= world || !strip_rows || world > kMaxRanks)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_comm_init: rank %u / world %u (1..%u) / strip %u", rank, world, kMaxRanks, strip_rows);
+  if (ctx->comm) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_comm_init: the context already has a communicator");
+  std::string why;
+  const RcclApi &api = rccl_api(&why);
+  if (!api.ok()) return fail(ctx, RT_ERR_NOT_READY, "rt_comm_init: no RCCL library could be loaded (%s)", why.c_str());
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof id);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t rc = api.CommInitRank(&comm, static_cast<int>(world), id, static_cast<int>(rank));  // collective: all ranks
+  if (rc != ncclSuccess) return fail(ctx, RT_ERR_DEVICE, "ncclCommInitRank (%s) failed: %s", api.path.c_str(), api.GetErrorString(rc));
+  if (!ctx->comm_stream) {
+    if (hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking) != hipSuccess) {
+      (void)api.CommDestroy(comm);
+      return fail(ctx, RT_ERR_DEVICE, "rt_comm_init: stream creation failed");
+    }
+    for (int i = 0; i < 2; ++i)
+      if (hipEventCreateWithFlags(&ctx->frame_ready[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&ctx->gather_done[i], hipEventDisableTiming) != hipSuccess) {
+        (void)api.CommDestroy(comm);
+        return fail(ctx, RT_ERR_DEVICE, "rt_comm_init: event creation failed");
+      }
+  }
+  ctx->comm = comm;
+  ctx->comm_rank = rank;
+  ctx->comm_world = world;
+  ctx->comm_launches = 0;
+  ctx->rank = rank;
+  ctx->world = world;
+  ctx->strip_rows = strip_rows;
+  return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
+}
+
+int rt_comm_destroy(rt_context *ctx) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!ctx->comm) return RT_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+  std::string why;
+  const RcclApi &api = rccl_api(&why);
+  if (api.ok()) (void)api.CommDestroy(ctx->comm);
+  ctx->comm = nullptr;
+  ctx->comm_world = 0;
+  ctx->comm_rank = 0;
+  ctx->rank = 0;
+  ctx->world = 1;
+  return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
+}
+
+int rt_read_frame_rgba8(rt_context *ctx, void *dst, size_t bytes) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!dst) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_read_frame_rgba8: dst is NULL");
+  if (!ctx->comm) return rt_read_rgba8(ctx, dst, bytes);  // one GPU: the local rows are the frame
+  if (ctx->comm_rank != 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_read_frame_rgba8: the frame is assembled on rank 0 only");
+  if (!ctx->d_frame) return fail(ctx, RT_ERR_NOT_READY, "rt_read_frame_rgba8: no target allocated");
+  const size_t need = static_cast<size_t>(ctx->width) * ctx->height * 4;
+  if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_read_frame_rgba8: %zu bytes given, %zu expected", bytes, need);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_frame, bytes, hipMemcpyDeviceToHost, ctx->comm_stream));  // behind the last gather
+  RT_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+  return RT_OK;
+}
+
+int rt_assemble_strips(rt_context *ctx, uint32_t width, uint32_t height, uint32_t world, uint32_t strip_rows, const void *rank0_rows,
+                       const void *peer_rows, void *frame) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!width || !height || !world || world > kMaxRanks || !strip_rows || !rank0_rows || !frame || (world > 1 && !peer_rows))
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_assemble_strips: bad arguments");
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  AssembleParams ap{};
+  const size_t peer_px = fill_assemble_layout(ap, width, height, world, strip_rows);
+  const size_t own_px = static_cast<size_t>(count_local_rows(height, 0, world, strip_rows)) * width;
+  const size_t frame_px = static_cast<size_t>(width) * height;
+  uint32_t *d_own = nullptr, *d_stack = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc(&d_own, own_px * 4 + 4);
+  if (e == hipSuccess) e = hipMalloc(&d_stack, peer_px * 4 + 4);
+  if (e == hipSuccess) e = hipMalloc(&d_out, frame_px * 4);
+  if (e == hipSuccess) e = hipMemcpy(d_own, rank0_rows, own_px * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && peer_px) e = hipMemcpy(d_stack, peer_rows, peer_px * 4, hipMemcpyHostToDevice);
+  int rc = 0;
+  if (e == hipSuccess) {
+    ap.frame = d_out;
+    ap.own = d_own;
+    ap.stack = d_stack;
+    rc = launch_assemble(ap, ctx->stream);
+    e = hipStreamSynchronize(ctx->stream);
+  }
+  if (rc == 0 && e == hipSuccess) e = hipMemcpy(frame, d_out, frame_px * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d_own);
+  (void)hipFree(d_stack);
+  (void)hipFree(d_out);
+  if (rc != 0 || e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "rt_assemble_strips failed: %s", hipGetErrorString(e));
+  return RT_OK;
 }
 
 int rt_set_accum_mode(rt_context *ctx, int mode) {
@@ -627,6 +804,44 @@ int rt_selftest_sqrt(rt_context *ctx, uint64_t *mismatches) {
   return RT_OK;
 }
 
+// The exchange step of a tile-split frame: after the launch that wrote send buffer `b`, every peer
+// sends its strips straight to rank 0 — grouped ncclSend / ncclRecv, one xGMI link per peer, no ring, no
+// all-gather — on the communication stream, so it runs beside the next launch's rendering; rank 0 then
+// interleaves the strips into the frame.
+static int gather_frame(rt_context *ctx, int b) {
+  std::string why;
+  const RcclApi &api = rccl_api(&why);
+  if (!api.ok()) return fail(ctx, RT_ERR_DEVICE, "RCCL is gone: %s", why.c_str());
+  uint32_t *bufs[2] = {ctx->d_rgba8, ctx->d_rgba8_alt};
+  RT_HIP(ctx, hipEventRecord(ctx->frame_ready[b], ctx->stream));
+  RT_HIP(ctx, hipStreamWaitEvent(ctx->comm_stream, ctx->frame_ready[b], 0));
+  const size_t row_bytes = static_cast<size_t>(ctx->width) * 4;
+  ncclResult_t rc = ncclSuccess;
+  if (ctx->comm_rank != 0) {
+    if (ctx->local_rows) rc = api.Send(bufs[b], ctx->local_rows * row_bytes, ncclUint8, 0, ctx->comm, ctx->comm_stream);
+  } else {
+    AssembleParams ap{};
+    fill_assemble_layout(ap, ctx->width, ctx->height, ctx->comm_world, ctx->strip_rows);
+    rc = api.GroupStart();
+    for (uint32_t r = 1; r < ctx->comm_world && rc == ncclSuccess; ++r)
+      if (ctx->rank_rows[r])
+        rc = api.Recv(ctx->d_stack + ap.stack_offset[r], ctx->rank_rows[r] * row_bytes, ncclUint8, static_cast<int>(r), ctx->comm,
+                      ctx->comm_stream);
+    const ncclResult_t rc2 = api.GroupEnd();
+    if (rc == ncclSuccess) rc = rc2;
+    if (rc == ncclSuccess) {
+      ap.frame = ctx->d_frame;
+      ap.own = bufs[b];
+      ap.stack = ctx->d_stack;
+      if (launch_assemble(ap, ctx->comm_stream) != 0) return fail(ctx, RT_ERR_DEVICE, "assemble launch failed");
+    }
+  }
+  if (rc != ncclSuccess) return fail(ctx, RT_ERR_DEVICE, "RCCL gather failed: %s", api.GetErrorString(rc));
+  RT_HIP(ctx, hipEventRecord(ctx->gather_done[b], ctx->comm_stream));
+  ctx->gather_pending[b] = true;
+  return RT_OK;
+}
+
 // One launch of `batch` frames (1 = the plain rt_render): jitter {x, y} and progressive count per frame.
 static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, const uint32_t *counts) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
@@ -694,6 +909,15 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   fp.rgba8 = ctx->ext_rgba8 ? ctx->ext_rgba8 : ctx->d_rgba8;
   fp.hist_rgba8 = ctx->ext_rgba8 ? (ctx->ext_hist_rgba8 ? ctx->ext_hist_rgba8 : ctx->ext_rgba8) : ctx->d_rgba8;
   fp.rgbf32 = ctx->ext_rgba8 ? ctx->ext_rgbf32 : ctx->d_rgbf32;
+  const int send = static_cast<int>(ctx->comm_launches & 1u);
+  if (ctx->comm) {  // alternate targets: the gather of this launch must not meet the next launch's writes
+    if (ctx->ext_rgba8) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render: rt_bind_outputs and rt_comm_init exclude each other");
+    uint32_t *bufs[2] = {ctx->d_rgba8, ctx->d_rgba8_alt};
+    fp.rgba8 = bufs[send];
+    fp.hist_rgba8 = bufs[send ^ 1];
+    // the gather that read this target two launches ago must be over before anything writes it again
+    if (ctx->gather_pending[send]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gather_done[send], 0));
+  }
   fp.hist_f32 = ctx->d_hist_f32;
   fp.segments = ctx->d_segments;
   fp.hits = ctx->d_hits;
@@ -822,6 +1046,12 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     ctx->resolve_pending[lane] = true;
     ctx->pipe_frames += 1;
   }
+  if (ctx->comm) {
+    const int grc = gather_frame(ctx, send);
+    if (grc != RT_OK) return grc;
+    ctx->last_send = send;
+    ctx->comm_launches += 1;
+  }
   ctx->stats.last_variant = static_cast<uint32_t>(variant_used);
   ctx->stats.last_stage = static_cast<uint32_t>(stage_used);
   ctx->stats.grid_cells = ctx->scene.grid.enabled ? ctx->scene.grid.n_cells : 0u;
@@ -870,18 +1100,23 @@ int rt_sync(rt_context *ctx) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   RT_HIP(ctx, hipSetDevice(ctx->device));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_stream) RT_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));  // the gather of the last launch too
   return RT_OK;
 }
 
-int rt_read_rgba8(rt_context *ctx, void *dst, size_t bytes) {  // caller-bound buffers take precedence
-  return read_back(ctx, ctx ? (ctx->ext_rgba8 ? ctx->ext_rgba8 : ctx->d_rgba8) : nullptr, dst, bytes, 4, "rt_read_rgba8");
+static const uint32_t *current_texels(rt_context *ctx) {  // caller-bound buffers take precedence
+  if (!ctx) return nullptr;
+  if (ctx->ext_rgba8) return ctx->ext_rgba8;
+  return (ctx->comm && ctx->last_send) ? ctx->d_rgba8_alt : ctx->d_rgba8;  // comm mode: the target of the last launch
+}
+int rt_read_rgba8(rt_context *ctx, void *dst, size_t bytes) {
+  return read_back(ctx, current_texels(ctx), dst, bytes, 4, "rt_read_rgba8");
 }
 int rt_read_rgbf32(rt_context *ctx, float *dst, size_t bytes) {
   return read_back(ctx, ctx ? (ctx->ext_rgba8 ? ctx->ext_rgbf32 : ctx->d_rgbf32) : nullptr, dst, bytes, 12, "rt_read_rgbf32");
 }
 int rt_read_rgba8_rows(rt_context *ctx, uint32_t first_row, uint32_t n_rows, void *dst, size_t bytes) {
-  return read_back(ctx, ctx ? (ctx->ext_rgba8 ? ctx->ext_rgba8 : ctx->d_rgba8) : nullptr, dst, bytes, 4, "rt_read_rgba8_rows",
-                   first_row, n_rows);
+  return read_back(ctx, current_texels(ctx), dst, bytes, 4, "rt_read_rgba8_rows", first_row, n_rows);
 }
 int rt_read_rgbf32_rows(rt_context *ctx, uint32_t first_row, uint32_t n_rows, float *dst, size_t bytes) {
   return read_back(ctx, ctx ? (ctx->ext_rgba8 ? ctx->ext_rgbf32 : ctx->d_rgbf32) : nullptr, dst, bytes, 12,
@@ -910,6 +1145,8 @@ int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes) {
   if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_write_history_rgba8: %zu bytes given, %zu expected", bytes, need);
   RT_HIP(ctx, hipSetDevice(ctx->device));
   uint32_t *history = ctx->ext_rgba8 ? (ctx->ext_hist_rgba8 ? ctx->ext_hist_rgba8 : ctx->ext_rgba8) : ctx->d_rgba8;
+  if (ctx->comm && !ctx->ext_rgba8)  // the next launch reads the buffer it does not write
+    history = (ctx->comm_launches & 1u) ? ctx->d_rgba8 : ctx->d_rgba8_alt;
   RT_HIP(ctx, hipMemcpyAsync(history, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RT_OK;

@@ -8,8 +8,11 @@ compact strip buffer straight to the root (RCCL lowers ``gather`` to grouped
 send/recv, one xGMI link per peer), never a ring.  PyTorch is used for device memory,
 streams and the process group only.
 
-``FrameGatherer`` is backend-agnostic (gloo/CPU in the unit tests, nccl/GPU in
-production); ``TileParallelRenderer`` binds it to an rt355 ``Device``.
+``TileParallelRenderer`` is the production path: the gather runs INSIDE ``librt355.so`` (``rt_comm_init``:
+grouped ncclSend / ncclRecv to rank 0 on a communication stream of the context, double-buffered targets, strips
+interleaved by a kernel on rank 0) — ``torch.distributed`` only carries the 128-byte communicator id to the other
+ranks.  ``FrameGatherer`` / ``TorchTileRenderer`` do the same composition with ``torch.distributed`` collectives
+(gloo/CPU in the unit tests, or a rehearsal with several ranks on one GPU).
 """
 from __future__ import annotations
 
@@ -79,8 +82,10 @@ class FrameGatherer:
         return flat.index_select(0, self.row_source)
 
 
-class TileParallelRenderer:
-    """rt355 ``Device`` + ``FrameGatherer``: renders this rank's strips on the current torch
+class TorchTileRenderer:
+    """The gather through ``torch.distributed`` instead of the library's own RCCL path — for rehearsals where RCCL
+    cannot run (several ranks sharing one GPU: gloo, staged through host memory) and as a second, independent
+    composition to test against.  rt355 ``Device`` + ``FrameGatherer``: renders this rank's strips on the current torch
     stream into double-buffered send tensors and gathers the sRGB8 texels on rank 0.
 
     Pipeline per ``render`` call k (so that gather(k-1) runs beside render(k)):
@@ -151,3 +156,52 @@ class TileParallelRenderer:
         frame = self._collect()
         torch.cuda.current_stream(self.torch_device).synchronize()
         return frame
+
+
+class TileParallelRenderer:
+    """One process per GPU, the image gather inside the C-ABI library (``rt_comm_init``, ``include/rt355.h``).
+
+    Every rank issues the same ``render`` calls; after each launch the rank's strips travel to rank 0 over RCCL
+    beside the next launch's rendering.  ``finish`` waits and returns the assembled (height, width, 4) uint8 frame
+    on rank 0.  The process group (any backend) is used once, to hand rank 0's communicator id to the others."""
+
+    def __init__(self, rt_device, width: int, height: int, strip_rows: int = 8, group=None):
+        self.rt = rt_device
+        self.width, self.height = width, height
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ident = [type(rt_device).comm_unique_id() if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        rt_device.comm_init(ident[0], self.rank, self.world, strip_rows)
+        self._render = rt_device._lib.rt_render
+        self._render_frames = rt_device._lib.rt_render_frames
+
+    def render(self, connection, jitter, progressive_count: int = 0):
+        """Launch one frame, or — ``jitter`` a sequence of n pairs — n consecutive frames of the accumulation in one
+        launch (counts progressive_count, +1, ...); the gather of this launch overlaps the next one."""
+        jit = np.asarray(jitter, dtype=np.float32)
+        if jit.ndim == 1:
+            rc = self._render(self.rt.handle, float(jit[0]), float(jit[1]), progressive_count)
+            last = (float(jit[0]), float(jit[1]), progressive_count)
+        else:
+            n = jit.shape[0]
+            blob = np.zeros((n, 4), dtype=np.uint32)  # FrameData: jitter f32 x2, progressive_count u32, pad
+            blob[:, :2] = jit.view(np.uint32)
+            blob[:, 2] = np.arange(progressive_count, progressive_count + n, dtype=np.uint32)
+            rc = self._render_frames(self.rt.handle, n, blob.ctypes.data)
+            last = (float(jit[-1, 0]), float(jit[-1, 1]), progressive_count + n - 1)
+        self.rt._check(rc, "rt_render")
+        connection.frame_data.jitter = last[:2]
+        connection.frame_data.progressive_count = last[2]
+        return None
+
+    def finish(self, read: bool = False):
+        """Wait for rendering and the last gather; with ``read`` rank 0 gets the assembled frame."""
+        self.rt.sync()
+        if read and self.rank == 0:
+            return self.rt.read_frame_rgba8(self.width, self.height)
+        return None
+
+    def close(self):
+        self.rt.comm_destroy()

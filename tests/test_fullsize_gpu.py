@@ -164,3 +164,38 @@ def test_tile_parallel_two_ranks_sharing_this_gpu():
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "REHEARSAL OK" in p.stdout
+
+
+def test_comm_path_of_the_c_abi_world_1():
+    """tools/comm_rehearsal.py: rt_comm_get_unique_id / rt_comm_init / the RCCL gather inside librt355 / rt_read_frame_rgba8
+    with a one-rank communicator on this GPU — single frames (two in flight), multi-frame launches, both accumulation
+    modes, a ragged frame size — bit-identical to the oracle's frame chain.  Own process (RCCL state)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "comm_rehearsal.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "COMM OK: world 1" in p.stdout
+
+
+@pytest.mark.parametrize("world,strip", [(2, 8), (3, 8), (8, 8), (5, 3)])
+def test_rank0_assembly_of_a_tile_split_frame(device, world, strip):
+    """What rank 0 does with the strips it receives (rt_assemble_strips = the gather's own layout function and
+    kernel, fed from the host): every rank's strips rendered with rt_set_partition on this GPU, the peers' rows
+    concatenated in rank order as the grouped ncclRecv delivers them -> the single-GPU frame, bit for bit.  A ragged
+    height, so that ranks own different row counts and the last strip is short."""
+    import ctypes as C
+    scene = cases.headline_scene(4)
+    size = (203, 117)
+    full = render(device, scene, size, (0.2, -0.3))[0].read_rgba8()
+    pieces = [render(device, scene, size, (0.2, -0.3), partition=(r, world, strip))[0].read_rgba8() for r in range(world)]
+    device.set_partition(0, 1, 8)
+    assert sum(p.shape[0] for p in pieces) == size[1]
+    peers = np.ascontiguousarray(np.concatenate(pieces[1:], axis=0)) if world > 1 else np.zeros((1, size[0], 4), np.uint8)
+    own = np.ascontiguousarray(pieces[0])
+    out = np.zeros((size[1], size[0], 4), np.uint8)
+    device.call("rt_assemble_strips", size[0], size[1], world, strip, own.ctypes.data_as(C.c_void_p),
+                peers.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out, full)
+    assert np.array_equal(out, assemble_rows(pieces, size[1], strip))  # the host-side mirror agrees

@@ -203,10 +203,10 @@ def test_kernel_sqrt_is_ieee_for_every_float(device):
 
 
 def test_tile_parallel_renderer_single_rank(device):
-    """TileParallelRenderer without a process group: caller-owned torch send buffers
+    """TorchTileRenderer without a process group: caller-owned torch send buffers
     (rt_bind_outputs), the torch stream (rt_set_stream) and double buffering, against the oracle."""
     import torch
-    from rsraytracingv3_amd.distributed import TileParallelRenderer
+    from rsraytracingv3_amd.distributed import TorchTileRenderer
     scene = cases.headline_scene(5)
     sky, rnd = cases.inputs(256, 128)
     size = (150, 93)
@@ -219,7 +219,7 @@ def test_tile_parallel_renderer_single_rank(device):
     rt.write(rnd)
     conn = Connection(scene, device, sky, rt)
     conn.update_buffers(size, scene, (0.0, 0.0))
-    tiles = TileParallelRenderer(device, size[0], size[1], strip_rows=8)
+    tiles = TorchTileRenderer(device, size[0], size[1], strip_rows=8)
     try:
         jit = [(0.2, 0.1), (-0.4, 0.3), (0.05, -0.45)]
         history = None

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """RCCL smoke test of the multi-GPU composition on ONE GPU: a world-size-1 nccl process group, the gather
-forced through torch.distributed (FrameGatherer.force_collective), TileParallelRenderer's pipeline compared
+forced through torch.distributed (FrameGatherer.force_collective), TorchTileRenderer's pipeline compared
 with plain single-context frames bit for bit.  It exercises every API call the N>1 bench makes (async
 gather into unbound views of the stack, work.wait(), index_select) with the real backend."""
 import os
@@ -15,7 +15,7 @@ import torch.distributed as dist  # noqa: E402
 import cases  # noqa: E402
 from rsraytracingv3_amd import Connection, Device, RandomTexture, RenderTarget, synth  # noqa: E402
 from rsraytracingv3_amd import _native as N  # noqa: E402
-from rsraytracingv3_amd.distributed import TileParallelRenderer  # noqa: E402
+from rsraytracingv3_amd.distributed import TorchTileRenderer  # noqa: E402
 
 
 def main():
@@ -40,7 +40,7 @@ def main():
         conn.frame_data.progressive_count = 0
         conn.draw()
         want.append(target.read_rgba8().copy())
-    tiles = TileParallelRenderer(dev, W, H, 8, force_collective=True)
+    tiles = TorchTileRenderer(dev, W, H, 8, force_collective=True)
     got = []
     for k in range(6):
         f = tiles.render(conn, jit[k], 0)

@@ -37,7 +37,7 @@ def main():
     import oracle
     from rsraytracingv3_amd import Connection, Device, RandomTexture, RenderTarget, synth
     from rsraytracingv3_amd import _native as N
-    from rsraytracingv3_amd.distributed import TileParallelRenderer
+    from rsraytracingv3_amd.distributed import TorchTileRenderer
     W, H = args.width, args.height
     scene = cases.headline_scene(6)
     sky, rnd = synth.procedural_skybox(256, 128), synth.random_texture(3)
@@ -48,7 +48,7 @@ def main():
     rt.write(rnd)
     conn = Connection(scene, dev, sky, rt)
     conn.update_buffers((W, H), scene, (0.0, 0.0))
-    tiles = TileParallelRenderer(dev, W, H, strip_rows=8)
+    tiles = TorchTileRenderer(dev, W, H, strip_rows=8)
     jit = synth.jitter_sequence(9, 3)
     frames = []
     for k in range(3):  # progressive_count 0 each: independent frames, gather(k-1) beside render(k)
