@@ -191,6 +191,14 @@ RT355_API int rt_render_frame(rt_context *ctx, const void *framedata16); /* same
  * GPU where one frame, or one rank's strips of it, cannot.  RT_OUT_SEGMENTS / RT_OUT_HITS describe a
  * single frame and must be off when n_frames > 1. */
 RT355_API int rt_render_frames(rt_context *ctx, uint32_t n_frames, const void *framedata16);
+/* Intermediate frames of a multi-frame launch.  The reference presents every frame (app.rs:240-253: copy to the
+ * history, refresh the egui texture); rt_render_frames leaves only the state after its last frame in the target.
+ * With rt_keep_batch_frames(ctx, every) the stored texels after frames every-1, 2*every-1, ... of each later
+ * launch are kept as well (exactly what n single rt_render_frame calls would have shown at those points) and
+ * rt_read_batch_frame(ctx, i, ...) reads frame i of the LAST launch (i + 1 a multiple of `every`; local rows,
+ * 4 bytes per texel).  every = 0 (default) keeps nothing; every = 1 keeps all n frames (n x the target's size). */
+RT355_API int rt_keep_batch_frames(rt_context *ctx, uint32_t every);
+RT355_API int rt_read_batch_frame(rt_context *ctx, uint32_t frame_in_launch, void *dst, size_t bytes);
 RT355_API int rt_sync(rt_context *ctx);
 
 /* `RenderTarget::update` hands the wgpu view to egui (render_target.rs:50-70); here the

@@ -73,6 +73,8 @@ SIGNATURES = {
     "rt_render": (_i, [_vp, _f, _f, _u32]),
     "rt_render_frame": (_i, [_vp, _vp]),
     "rt_render_frames": (_i, [_vp, C.c_uint32, _vp]),
+    "rt_keep_batch_frames": (_i, [_vp, _u32]),
+    "rt_read_batch_frame": (_i, [_vp, _u32, _vp, _sz]),
     "rt_sync": (_i, [_vp]),
     "rt_read_rgba8": (_i, [_vp, _vp, _sz]),
     "rt_read_rgbf32": (_i, [_vp, _vp, _sz]),

@@ -122,6 +122,10 @@ struct ResolveParams {
   float *hist_f32;
   const float *srgb_lut;
   int accum_mode;
+  // intermediate frames (rt_keep_batch_frames): the stored texels of frame f go to kept[(f / keep_every) * pixels + p]
+  // when (f + 1) % keep_every == 0; null = keep nothing
+  uint32_t *kept;
+  uint32_t keep_every;
 };
 
 // kernels (rt_kernels.hip)

@@ -1086,6 +1086,8 @@ __global__ void __launch_bounds__(256) resolve_batch_kernel(ResolveParams rp) {
     prev = rp.accum_mode == 1 ? mixed
                               : mk3(rp.srgb_lut[texel & 255u], rp.srgb_lut[(texel >> 8) & 255u],
                                     rp.srgb_lut[(texel >> 16) & 255u]);
+    if (rp.kept != nullptr && (f + 1u) % rp.keep_every == 0u)  // what the reference would have presented after frame f
+      rp.kept[static_cast<size_t>(f / rp.keep_every) * rp.pixels + p] = texel;
   }
   rp.rgba8[p] = texel;
   if (rp.rgbf32) {

@@ -104,6 +104,12 @@ struct rt_context {
   std::vector<uint32_t> rank_rows;                  // local rows of every rank
   uint64_t comm_launches = 0;
   int last_send = 0;  // send buffer the last launch wrote
+  // intermediate frames of multi-frame launches (rt_keep_batch_frames)
+  uint32_t keep_every = 0;
+  uint32_t *d_kept = nullptr;
+  size_t kept_cap = 0;       // in texels
+  uint32_t kept_frames = 0;  // frames the last launch kept
+  uint32_t kept_every_last = 0;
   int inflight = 2;
   int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid
   hipStream_t render_stream[2] = {nullptr, nullptr};
@@ -218,6 +224,7 @@ int alloc_target(rt_context *ctx) {
   free_target(ctx);
   ctx->local_rows = count_local_rows(ctx->height, ctx->rank, ctx->world, ctx->strip_rows);
   ctx->masks_dirty = true;
+  ctx->kept_frames = 0;
   const size_t px = static_cast<size_t>(ctx->local_rows) * ctx->width;
   if (px == 0) return RT_OK;
   const int rc = alloc_target_buffers(ctx, px);
@@ -365,6 +372,7 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_tile_counters);
   (void)hipFree(ctx->d_masks);
   (void)hipFree(ctx->d_samples);
+  (void)hipFree(ctx->d_kept);
   for (int i = 0; i < 2; ++i) {
     if (ctx->render_stream[i]) (void)hipStreamSynchronize(ctx->render_stream[i]);
     (void)hipFree(ctx->d_pipe_samples[i]);
@@ -964,6 +972,25 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     rp.hist_f32 = fp.hist_f32;
     rp.srgb_lut = fp.srgb_lut;
     rp.accum_mode = fp.accum_mode;
+    rp.kept = nullptr;
+    rp.keep_every = 1;
+    ctx->kept_frames = 0;
+    if (ctx->keep_every != 0u && batch > 1u && batch / ctx->keep_every != 0u) {
+      const uint32_t n_kept = batch / ctx->keep_every;
+      const size_t need_kept = static_cast<size_t>(n_kept) * rp.pixels;
+      if (ctx->kept_cap < need_kept) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_kept);
+        ctx->d_kept = nullptr;
+        ctx->kept_cap = 0;
+        RT_HIP(ctx, hipMalloc(&ctx->d_kept, need_kept * 4));
+        ctx->kept_cap = need_kept;
+      }
+      rp.kept = ctx->d_kept;
+      rp.keep_every = ctx->keep_every;
+      ctx->kept_frames = n_kept;
+      ctx->kept_every_last = ctx->keep_every;
+    }
     fp.progressive_count = 0;
     fp.opacity = 1.0f;
     fp.keep = 0.0f;
@@ -1135,6 +1162,29 @@ int rt_read_hits(rt_context *ctx, int32_t *dst, size_t bytes) {
     return fail(ctx, RT_ERR_NOT_READY, "rt_read_hits: the last frame was rendered with reflection_limit %u, the scene now "
                                        "has %u; render a frame first", ctx->hits_rendered_limit, ctx->config.reflection_limit);
   return read_back(ctx, ctx->d_hits, dst, bytes, 4 * static_cast<size_t>(ctx->hits_rendered_limit), "rt_read_hits");
+}
+
+int rt_keep_batch_frames(rt_context *ctx, uint32_t every) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  ctx->keep_every = every;
+  return RT_OK;
+}
+
+int rt_read_batch_frame(rt_context *ctx, uint32_t frame_in_launch, void *dst, size_t bytes) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!dst) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_read_batch_frame: dst is NULL");
+  if (!ctx->kept_frames || !ctx->d_kept)
+    return fail(ctx, RT_ERR_NOT_READY, "rt_read_batch_frame: the last launch kept no frames (rt_keep_batch_frames, rt_render_frames)");
+  if ((frame_in_launch + 1u) % ctx->kept_every_last != 0u || frame_in_launch / ctx->kept_every_last >= ctx->kept_frames)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_read_batch_frame: frame %u was not kept (every %u, %u kept)", frame_in_launch,
+                ctx->kept_every_last, ctx->kept_frames);
+  const size_t px = static_cast<size_t>(ctx->local_rows) * ctx->width;
+  if (bytes != px * 4) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_read_batch_frame: %zu bytes given, %zu expected", bytes, px * 4);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipMemcpyAsync(dst, ctx->d_kept + static_cast<size_t>(frame_in_launch / ctx->kept_every_last) * px, bytes,
+                             hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
 }
 
 int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes) {

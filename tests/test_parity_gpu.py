@@ -445,3 +445,51 @@ def test_two_frames_in_flight_equal_one_at_a_time_and_the_oracle(device, accum):
         hist8, histf = (None, ref.rgbf32) if accum == N.RT_ACCUM_FLOAT32 else (ref.rgba8, None)
     assert np.array_equal(results[2][0].view(np.uint32), ref.rgbf32.view(np.uint32))
     assert np.array_equal(results[2][1], ref.rgba8)
+
+
+@pytest.mark.parametrize("accum", [N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32])
+def test_intermediate_frames_of_a_batch_launch(device, accum):
+    """rt_keep_batch_frames: the reference presents every frame (app.rs:240-253); a multi-frame launch can keep the
+    stored texels after every k-th frame.  Kept frame i == the target after frames 0..i rendered one per launch."""
+    import ctypes as C
+    scene = cases.headline_scene(4)
+    size = (150, 93)
+    sky, rnd = cases.inputs(256, 128)
+    jit = synth.jitter_sequence(11, 6)
+
+    def setup():
+        device.set_partition(0, 1, 8)
+        device.set_accum_mode(accum)
+        device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
+        device.set_variant(-1)
+        target = RenderTarget.new(device, size)
+        rt = RandomTexture(device)
+        rt.write(rnd)
+        conn = Connection(scene, device, sky, rt, max_objects="live")
+        conn.update_buffers(size, scene, (0.0, 0.0))
+        return target, conn
+
+    target, conn = setup()
+    sequential = []
+    for k in range(6):
+        conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
+        conn.frame_data.progressive_count = k
+        conn.draw()
+        device.sync()
+        sequential.append(target.read_rgba8())
+    try:
+        for every in (1, 2, 3):
+            target, conn = setup()
+            device.call("rt_keep_batch_frames", every)
+            conn.draw_frames(jit, 0)
+            device.sync()
+            assert np.array_equal(target.read_rgba8(), sequential[5])
+            for i in range(6):
+                out = np.empty((size[1], size[0], 4), np.uint8)
+                rc = device._lib.rt_read_batch_frame(device.handle, i, out.ctypes.data_as(C.c_void_p), out.nbytes)
+                if (i + 1) % every == 0:
+                    assert rc == 0 and np.array_equal(out, sequential[i]), "every %d, frame %d" % (every, i)
+                else:
+                    assert rc == -1  # RT_ERR_INVALID_ARGUMENT: that frame was not kept
+    finally:
+        device.call("rt_keep_batch_frames", 0)
