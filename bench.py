@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tile-chunk", type=int, default=2)
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--grid-min", type=int, default=0, help="RT_OPT_GRID_MIN: spheres from which a scene gets the sphere grid (0 = library default 129)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive 1-spp frames per kernel launch (rt_render_frames, 1..64); 0 = 8 per GPU of the job, "
                          "so that a launch carries eight frames' worth of tiles whatever the partition")
@@ -124,6 +125,8 @@ def main():
     dev.set_option(N.RT_OPT_BLOCKS_PER_CU, args.blocks_per_cu)
     dev.set_option(N.RT_OPT_TILE_CHUNK, args.tile_chunk)
     dev.set_option(N.RT_OPT_FLAGS, args.flags)
+    if args.grid_min > 0:
+        dev.set_option(N.RT_OPT_GRID_MIN, args.grid_min)
     target = RenderTarget.new(dev, (W, H))
     rt = RandomTexture(dev)
     rt.write(rnd)
@@ -286,9 +289,13 @@ def main():
                 prof = json.load(f)
         except Exception:
             continue
-        if prof.get("workload_key") == workload_key and steps % B == 0:
-            traffic = prof.get("render_kernel", {}).get("hbm_bytes_per_launch")
-            traffic_resolve = prof.get("resolve_kernel", {}).get("hbm_bytes_per_launch")
+        if prof.get("workload_key") == workload_key:
+            # per launch of THIS run: the profile's bytes per frame x the frames an average launch of the block carried
+            frames_per_launch = float(steps) / launches
+            per_frame = prof.get("render_kernel", {}).get("hbm_bytes_per_frame")
+            traffic = round(per_frame * frames_per_launch, 1) if per_frame else None
+            per_frame = prof.get("resolve_kernel", {}).get("hbm_bytes_per_frame")
+            traffic_resolve = round(per_frame * frames_per_launch, 1) if per_frame else None
             issue_util = prof.get("render_kernel", {}).get("valu_issue_util")
     out = {
         "metric": "Mrays/s at 1920x1080, 64 spheres, 8 bounces",

@@ -10,14 +10,14 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$REPO/bench.py" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 echo "stats pass done"
 i=0
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_HIT_sum TCC_MISS_sum" \
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU" \
-           "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+           "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i + 1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc$i" -o pmc -- python3 "$REPO/bench.py" --no-cpu-baseline --steps 48 --warmup 16 > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.log"
+  rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc$i" -o pmc -- python3 "$REPO/bench.py" --no-cpu-baseline --no-extra-legs --steps 48 --warmup 16 --min-seconds 0.05 --clock-warmup 0.2 > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.log"
   echo "pmc pass $i ($set) done"
 done
 cd "$REPO"
-python3 tools/pmc_summary.py "$OUT"/pmc[0-9] --json "$OUT/traffic.json" --workload "bench.py default" > "$OUT/pmc_summary.txt"
+python3 tools/pmc_summary.py "$OUT"/pmc[0-9] --json "$OUT/traffic.json" > "$OUT/pmc_summary.txt"
 cat "$OUT/pmc_summary.txt"
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cat {} \;
