@@ -14,6 +14,7 @@ import collections
 import csv
 import glob
 import json
+import re
 
 ap = argparse.ArgumentParser()
 ap.add_argument("dirs", nargs="+")
@@ -36,7 +37,8 @@ for d in args.dirs:
             for key, pat in KERNELS.items():
                 if pat in r["Kernel_Name"]:
                     acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    names[key].add(r["Kernel_Name"].split("(")[0].split("::")[-1])
+                    m = re.search(r"(render_\w+(?:<\d+>)?|resolve_batch_kernel)", r["Kernel_Name"])
+                    names[key].add(m.group(1) if m else r["Kernel_Name"])
         for key in KERNELS:
             # launches of the warm-up may carry fewer frames; keep the modal half (the timed launches) by median
             for c, v in acc[key].items():

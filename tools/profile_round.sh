@@ -7,8 +7,12 @@ OUT=$(realpath -m "$1")
 REPO=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$REPO/bench.py" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
-echo "stats pass done"
+# the headline leg only (--no-extra-legs), so that every render launch of the trace carries the 8 frames the JSON line's
+# roofline.avg_launch_ms is about; the full default line (with the extra legs) is traced separately
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$REPO/bench.py" --no-extra-legs > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
+echo "stats pass (headline leg) done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_all_legs" -o bench -- python3 "$REPO/bench.py" --no-cpu-baseline > "$OUT/bench_all_legs_under_rocprof.json" 2> "$OUT/stats_all_legs.log"
+echo "stats pass (all legs) done"
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU" \
@@ -20,4 +24,4 @@ done
 cd "$REPO"
 python3 tools/pmc_summary.py "$OUT"/pmc[0-9] --json "$OUT/traffic.json" > "$OUT/pmc_summary.txt"
 cat "$OUT/pmc_summary.txt"
-find "$OUT/stats" -name "*kernel_stats.csv" -exec cat {} \;
+find "$OUT/stats" -name "*kernel_stats.csv" -exec head -4 {} \;
