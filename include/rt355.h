@@ -249,9 +249,10 @@ enum {
   RT_OPT_FLAGS = 4,        /* experiment switches (speed only)                                     */
   RT_OPT_CULL = 5,         /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
                               scan is re-done in full and disagreements are counted in rt_stats     */
-  RT_OPT_INFLIGHT = 6,     /* single-frame launches (rt_render / rt_render_frame) in flight at once: 2 (default)
-                              = frame k + 1 starts rendering on a second internal stream while the last
-                              workgroups of frame k drain — the reference's loop issues one frame per turn
+  RT_OPT_INFLIGHT = 6,     /* single-frame launches (rt_render / rt_render_frame) in flight at once, 1..8 (default 4):
+                              frame k + 1 starts rendering on another internal stream while the last
+                              workgroups of frame k drain (a whole 1080p frame gains nothing beyond 2; the small
+                              launches of a rank's strips of a tile-split frame gain up to 4) — the reference's loop issues one frame per turn
                               (app.rs:208-254) and one 1080p frame leaves a fifth of the GPU idle during its
                               ramp-up and tail; the history is still updated strictly in frame order on the
                               context's stream.  1 = one launch at a time (kernel times do not overlap).     */

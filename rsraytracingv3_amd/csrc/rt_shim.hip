@@ -87,10 +87,10 @@ struct rt_context {
   bool masks_dirty = true;  // scene, size or partition changed since the masks were built
   float *d_samples = nullptr;  // staging of a batch's float samples (rt_render_frames), batch x padded rows x W x 3
   size_t samples_cap = 0;      // in floats
-  // Two single-frame launches in flight (RT_OPT_INFLIGHT = 2): frame k renders its float sample on render
-  // stream k % 2 into pipe_samples[k % 2] while the tail of frame k - 1 drains on the other stream; the main
-  // stream waits for each render in order and folds the sample into the history (resolve), so the history chain
-  // and everything the caller sees stay in frame order.
+  // Several single-frame launches in flight (RT_OPT_INFLIGHT = n, default 4): frame k renders its float sample
+  // on render stream k % n into pipe_samples[k % n] while the tails of the frames before it drain on the other
+  // streams; the main stream waits for each render in order and folds the sample into the history (resolve), so
+  // the history chain and everything the caller sees stay in frame order.
   // Multi-GPU frame (rt_comm_init): this context is rank comm_rank of comm_world; after every launch its strips
   // go to rank 0 over RCCL on comm_stream, beside the next launch.  Launch k renders into send[k & 1] with
   // send[(k & 1) ^ 1] as its history, so the gather of launch k reads a buffer launch k + 1 does not write.
@@ -110,14 +110,15 @@ struct rt_context {
   size_t kept_cap = 0;       // in texels
   uint32_t kept_frames = 0;  // frames the last launch kept
   uint32_t kept_every_last = 0;
-  int inflight = 2;
+  static constexpr int kMaxInflight = 8;
+  int inflight = 4;
   int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid
-  hipStream_t render_stream[2] = {nullptr, nullptr};
-  hipEvent_t render_done[2] = {nullptr, nullptr}, resolve_done[2] = {nullptr, nullptr}, prep_done = nullptr;
-  bool resolve_pending[2] = {false, false};  // resolve_done[i] has been recorded since pipe_samples[i] was written
-  bool prep_pending = false;                 // work the renders depend on was queued on the main stream (prep_done)
-  float *d_pipe_samples[2] = {nullptr, nullptr};
-  size_t pipe_cap[2] = {0, 0};  // in floats
+  hipStream_t render_stream[kMaxInflight] = {};
+  hipEvent_t render_done[kMaxInflight] = {}, resolve_done[kMaxInflight] = {}, prep_done = nullptr;
+  bool resolve_pending[kMaxInflight] = {};  // resolve_done[i] has been recorded since pipe_samples[i] was written
+  bool prep_pending = false;                // work the renders depend on was queued on the main stream (prep_done)
+  float *d_pipe_samples[kMaxInflight] = {};
+  size_t pipe_cap[kMaxInflight] = {};  // in floats
   uint64_t pipe_frames = 0;
   rt_stats stats{};
   std::string error;
@@ -324,7 +325,7 @@ int rt_create(int device_id, rt_context **out_ctx) {
       return bail(RT_ERR_DEVICE);
   for (int i = 0; i < 2; ++i)
     if (hipEventCreateWithFlags(&ctx->rnd_last_use[i], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < rt_context::kMaxInflight; ++i)
     if (hipStreamCreateWithFlags(&ctx->render_stream[i], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->render_done[i], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->resolve_done[i], hipEventDisableTiming) != hipSuccess)
@@ -373,7 +374,7 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_masks);
   (void)hipFree(ctx->d_samples);
   (void)hipFree(ctx->d_kept);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < rt_context::kMaxInflight; ++i) {
     if (ctx->render_stream[i]) (void)hipStreamSynchronize(ctx->render_stream[i]);
     (void)hipFree(ctx->d_pipe_samples[i]);
     if (ctx->render_done[i]) (void)hipEventDestroy(ctx->render_done[i]);
@@ -786,8 +787,9 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       ctx->grid_min_spheres = value < 1 ? 1 : value;
       return RT_OK;
     case RT_OPT_INFLIGHT:
-      if (value < 1 || value > 2) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_INFLIGHT takes 1 or 2");
-      ctx->inflight = value;
+      if (value < 1 || value > rt_context::kMaxInflight)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_INFLIGHT takes 1..%d", rt_context::kMaxInflight);
+      ctx->inflight = value;  // a frame already in flight keeps its lane: lanes are only re-used after their resolve
       return RT_OK;
     default:
       return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
@@ -940,7 +942,7 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   // Single frames keep two launches in flight (see rt_context::inflight) unless a per-frame diagnostic output
   // (segments, hits) is on: those buffers describe ONE frame and two kernels must not write them at once.
   const bool pipelined = batch == 1u && ctx->inflight >= 2 && !(ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS));
-  const int lane = static_cast<int>(ctx->pipe_frames & 1u);
+  const int lane = static_cast<int>(ctx->pipe_frames % static_cast<uint64_t>(ctx->inflight < 1 ? 1 : ctx->inflight));
   hipStream_t render_stream = pipelined ? ctx->render_stream[lane] : ctx->stream;
   float *staging = nullptr;
   if (batch > 1u || pipelined) {

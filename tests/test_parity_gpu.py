@@ -406,7 +406,7 @@ def test_batch_launch_limits(device):
 
 @pytest.mark.parametrize("accum", [N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32])
 def test_two_frames_in_flight_equal_one_at_a_time_and_the_oracle(device, accum):
-    """RT_OPT_INFLIGHT = 2 (default): single-frame launches (the reference's one draw per loop turn,
+    """RT_OPT_INFLIGHT (default 4; here 4, 2 and 1): single-frame launches (the reference's one draw per loop turn,
     app.rs:208-254) alternate between two internal streams so that frame k + 1 starts while frame k drains; the
     history is folded in frame order.  12 frames without a sync in between, the random texture replaced on the
     device every 4 frames: same texels and floats as one launch at a time, and as the oracle's frame chain."""
@@ -415,7 +415,7 @@ def test_two_frames_in_flight_equal_one_at_a_time_and_the_oracle(device, accum):
     sky, _ = cases.inputs(256, 128)
     jit = synth.jitter_sequence(9, 12)
     results = {}
-    for inflight in (2, 1):
+    for inflight in (4, 2, 1):
         device.set_partition(0, 1, 8)
         device.set_accum_mode(accum)
         device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
@@ -435,7 +435,8 @@ def test_two_frames_in_flight_equal_one_at_a_time_and_the_oracle(device, accum):
             conn.draw()
         device.sync()
         results[inflight] = (target.read_rgbf32(), target.read_rgba8())
-    device.set_option(N.RT_OPT_INFLIGHT, 2)
+    device.set_option(N.RT_OPT_INFLIGHT, 4)
+    assert np.array_equal(results[4][0].view(np.uint32), results[1][0].view(np.uint32)) and np.array_equal(results[4][1], results[1][1])
     assert np.array_equal(results[2][0].view(np.uint32), results[1][0].view(np.uint32))
     assert np.array_equal(results[2][1], results[1][1])
     hist8 = histf = None
