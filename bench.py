@@ -134,11 +134,30 @@ def main():
     conn.update_buffers((W, H), scene, (0.0, 0.0))
 
     tiles = None
+    gather_path = None
     if world > 1:
         from rsraytracingv3_amd.distributed import TileParallelRenderer, TorchTileRenderer
         # production: the gather inside librt355 over RCCL; a gloo rehearsal (ranks sharing one GPU, which RCCL
         # refuses) gathers through torch.distributed and host memory instead
-        tiles = (TileParallelRenderer if args.backend == "nccl" else TorchTileRenderer)(dev, W, H, args.strip_rows)
+        gather_path = "rt_comm_init: RCCL send/recv inside librt355"
+        if args.backend == "nccl":
+            try:
+                tiles = TileParallelRenderer(dev, W, H, args.strip_rows)
+                failed = 0.0
+            except Exception as exc:  # reported, never silent: the line says which transport carried the gather
+                gather_path = "torch.distributed.gather (TorchTileRenderer) — rt_comm_init FAILED on rank %d: %s" % (rank, exc)
+                failed = 1.0
+            flag = torch.tensor([failed], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # every rank takes the same path
+            if flag.item() > 0.0:
+                if failed == 0.0:
+                    tiles.close()
+                    gather_path = "torch.distributed.gather (TorchTileRenderer) — rt_comm_init failed on another rank"
+                print("bench.py rank %d: %s" % (rank, gather_path), file=sys.stderr, flush=True)
+                tiles = TorchTileRenderer(dev, W, H, args.strip_rows)
+        else:
+            gather_path = "torch.distributed.gather over %s, staged through host memory (rehearsal)" % args.backend
+            tiles = TorchTileRenderer(dev, W, H, args.strip_rows)
 
     def run_frames(first, count, B):
         """frames first .. first+count-1 of the accumulation, B per launch; returns the number of launches"""
@@ -236,7 +255,7 @@ def main():
     # ---- extra legs: one frame per launch (reference call pattern); 80 zero-padded slots ------------------
     def leg_summary(leg, frames_per_launch):
         blk = leg["block"]
-        return {"frames_per_launch": frames_per_launch, "launches_in_flight": 4 if frames_per_launch == 1 and (world == 1 or args.backend == "nccl") else 1,
+        return {"frames_per_launch": frames_per_launch, "launches_in_flight": 4 if frames_per_launch == 1 else 1,
                 "steps": args.steps,
                 "ms_per_step": round(leg["elapsed"] / args.steps * 1e3, 5),
                 "mrays_per_s": round(leg["total_seg"] / leg["elapsed"] / 1e6, 2),
@@ -314,8 +333,8 @@ def main():
             "workload": "%dx%d, %d spheres + ground plane (%d object slots), %d bounces, 1 spp, %dx%d RGBA32F skybox"
                         % (W, H, args.spheres, n_objects, args.bounces, args.sky, args.sky // 2),
             "partition": "row strips of %d, round-robin over %d GPU(s)%s" % (
-                args.strip_rows, world, ", RCCL gather to rank 0 inside librt355 (rt_comm_init: grouped ncclSend/ncclRecv on "
-                "a communication stream, beside the next launch)" if world > 1 else ""),
+                args.strip_rows, world, ", strips gathered on rank 0 after every launch, beside the next one" if world > 1 else ""),
+            "gather": gather_path,
             "headline_mode": "%d consecutive frames of the accumulation per launch (8 per GPU), one gather per launch; the "
                              "one_frame_per_launch leg is the per-frame figure (one launch and one gather per frame)" % B,
             "kernel_variant": args.variant,

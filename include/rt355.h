@@ -263,6 +263,17 @@ enum {
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */
 
+/* The sphere grid rt_set_scene builds for large scenes (RT_OPT_GRID_MIN), exposed for inspection and for testing its
+ * registration rule without a GPU: host code only.  spheres = n x {cx, cy, cz, r*r}; cell_start gets n_cells + 1
+ * entries, items n_items sphere indices (when the capacities given suffice; call once with null arrays for the
+ * sizes).  info->enabled = 0 when no grid is built (too few spheres, non-finite data, or too many entries). */
+typedef struct rt_grid_info {
+  uint32_t enabled, nx, ny, nz, n_cells, n_items;
+  float gmin[3], gmax[3], cell[3], inv_cell[3], near_min[3], near_max[3], t_margin;
+} rt_grid_info;
+RT355_API int rt_grid_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t min_spheres, rt_grid_info *info,
+                                 uint32_t *cell_start, uint32_t cell_cap, uint16_t *items, uint32_t item_cap);
+
 /* Device self-test hooks used by the parity tests: evaluate the device build of the
  * specified math function over n host values (op: 0 sin 1 cos 2 tan 3 asin 4 log2
  * 5 exp2 6 sqrt 7 the kernel's own sqrt; binary op: 0 atan2(a,b) 1 pow(a,b) 2 a/b). */

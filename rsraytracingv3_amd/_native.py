@@ -38,6 +38,12 @@ class RtStats(C.Structure):
                 ("grid_cells", C.c_uint32), ("grid_items", C.c_uint32)]
 
 
+class RtGridInfo(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32), ("n_cells", C.c_uint32),
+                ("n_items", C.c_uint32), ("gmin", C.c_float * 3), ("gmax", C.c_float * 3), ("cell", C.c_float * 3),
+                ("inv_cell", C.c_float * 3), ("near_min", C.c_float * 3), ("near_max", C.c_float * 3), ("t_margin", C.c_float)]
+
+
 class RtDeviceBuffers(C.Structure):
     _fields_ = [("rgba8", C.c_void_p), ("rgbf32", C.c_void_p), ("segments", C.c_void_p), ("hits", C.c_void_p),
                 ("stream", C.c_void_p), ("width", C.c_uint32), ("local_rows", C.c_uint32)]
@@ -60,6 +66,7 @@ SIGNATURES = {
     "rt_set_scene": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
     "rt_resize": (_i, [_vp, _u32, _u32]),
     "rt_set_partition": (_i, [_vp, _u32, _u32, _u32]),
+    "rt_grid_build_host": (_i, [_vp, _u32, _u32, C.POINTER(RtGridInfo), _vp, _u32, _vp, _u32]),
     "rt_comm_get_unique_id": (_i, [_vp]),
     "rt_comm_init": (_i, [_vp, _vp, _u32, _u32, _u32]),
     "rt_comm_destroy": (_i, [_vp]),

@@ -633,6 +633,40 @@ int rt_set_partition(rt_context *ctx, uint32_t rank, uint32_t world, uint32_t st
   return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
 }
 
+int rt_grid_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t min_spheres, rt_grid_info *info, uint32_t *cell_start,
+                       uint32_t cell_cap, uint16_t *items, uint32_t item_cap) {
+  if (!info || (!spheres_xyzr2 && n_spheres)) return RT_ERR_INVALID_ARGUMENT;
+  try {
+    const size_t n_pad = (static_cast<size_t>(n_spheres) + kSphBatch - 1) / kSphBatch * kSphBatch + kSphBatch;
+    std::vector<float4> sph(n_pad, make_float4(0.0f, 0.0f, 0.0f, -INFINITY));
+    for (uint32_t i = 0; i < n_spheres; ++i)
+      sph[i] = make_float4(spheres_xyzr2[4 * i], spheres_xyzr2[4 * i + 1], spheres_xyzr2[4 * i + 2], spheres_xyzr2[4 * i + 3]);
+    const GridBuild g = build_grid(sph, n_spheres, n_pad, min_spheres);
+    std::memset(info, 0, sizeof *info);
+    info->enabled = g.params.enabled;
+    if (!g.params.enabled) return RT_OK;
+    info->nx = g.params.nx;
+    info->ny = g.params.ny;
+    info->nz = g.params.nz;
+    info->n_cells = g.params.n_cells;
+    info->n_items = g.params.n_items;
+    for (int a = 0; a < 3; ++a) {
+      info->gmin[a] = g.params.gmin[a];
+      info->gmax[a] = g.params.gmax[a];
+      info->cell[a] = g.params.cell[a];
+      info->inv_cell[a] = g.params.inv_cell[a];
+      info->near_min[a] = g.params.near_min[a];
+      info->near_max[a] = g.params.near_max[a];
+    }
+    info->t_margin = g.params.t_margin;
+    if (cell_start && cell_cap >= g.cell_start.size()) std::memcpy(cell_start, g.cell_start.data(), g.cell_start.size() * 4);
+    if (items && item_cap >= g.items.size()) std::memcpy(items, g.items.data(), g.items.size() * 2);
+    return RT_OK;
+  } catch (...) {
+    return RT_ERR_OUT_OF_MEMORY;
+  }
+}
+
 int rt_comm_get_unique_id(void *id128) {
   if (!id128) return RT_ERR_INVALID_ARGUMENT;
   std::string why;
