@@ -110,12 +110,17 @@ struct rt_context {
   size_t kept_cap = 0;       // in texels
   uint32_t kept_frames = 0;  // frames the last launch kept
   uint32_t kept_every_last = 0;
+  int occupancy_blocks = 0;          // cached hipOccupancyMaxActiveBlocksPerMultiprocessor answer for ...
+  uint32_t occupancy_records = ~0u;  // ... a scene image of this many records
   static constexpr int kMaxInflight = 8;
   int inflight = 4;
+  uint64_t prep_generation = 0;                 // bumped whenever prep_done is re-recorded
+  uint64_t prep_seen[kMaxInflight] = {};        // generation each render stream has already waited for
   int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid
   hipStream_t render_stream[kMaxInflight] = {};
-  hipEvent_t render_done[kMaxInflight] = {}, resolve_done[kMaxInflight] = {}, prep_done = nullptr;
-  bool resolve_pending[kMaxInflight] = {};  // resolve_done[i] has been recorded since pipe_samples[i] was written
+  hipEvent_t prep_done = nullptr;  // (the renders and resolves are joined on the per-launch timing events)
+  bool resolve_pending[kMaxInflight] = {};  // pipe_samples[i] has been written; its resolve is ev_resolved[resolve_slot[i]]
+  uint32_t resolve_slot[kMaxInflight] = {};
   bool prep_pending = false;                // work the renders depend on was queued on the main stream (prep_done)
   float *d_pipe_samples[kMaxInflight] = {};
   size_t pipe_cap[kMaxInflight] = {};  // in floats
@@ -326,10 +331,7 @@ int rt_create(int device_id, rt_context **out_ctx) {
   for (int i = 0; i < 2; ++i)
     if (hipEventCreateWithFlags(&ctx->rnd_last_use[i], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
   for (int i = 0; i < rt_context::kMaxInflight; ++i)
-    if (hipStreamCreateWithFlags(&ctx->render_stream[i], hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->render_done[i], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->resolve_done[i], hipEventDisableTiming) != hipSuccess)
-      return bail(RT_ERR_DEVICE);
+    if (hipStreamCreateWithFlags(&ctx->render_stream[i], hipStreamNonBlocking) != hipSuccess) return bail(RT_ERR_DEVICE);
   if (hipEventCreateWithFlags(&ctx->prep_done, hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
   if (hipMalloc(&ctx->d_counters, rt_context::kRing * rt_context::kCounterWords * sizeof(unsigned long long)) != hipSuccess)
     return bail(RT_ERR_OUT_OF_MEMORY);
@@ -377,8 +379,6 @@ int rt_destroy(rt_context *ctx) {
   for (int i = 0; i < rt_context::kMaxInflight; ++i) {
     if (ctx->render_stream[i]) (void)hipStreamSynchronize(ctx->render_stream[i]);
     (void)hipFree(ctx->d_pipe_samples[i]);
-    if (ctx->render_done[i]) (void)hipEventDestroy(ctx->render_done[i]);
-    if (ctx->resolve_done[i]) (void)hipEventDestroy(ctx->resolve_done[i]);
     if (ctx->render_stream[i]) (void)hipStreamDestroy(ctx->render_stream[i]);
   }
   if (ctx->prep_done) (void)hipEventDestroy(ctx->prep_done);
@@ -1075,18 +1075,28 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   if (prep_queued) {  // render streams must not start before the masks / re-armed counters are there
     RT_HIP(ctx, hipEventRecord(ctx->prep_done, ctx->stream));
     ctx->prep_pending = true;
+    ctx->prep_generation += 1;
   }
   if (pipelined) {
     // this lane's sample buffer is free once the resolve that read it (two frames ago) has run
-    if (ctx->resolve_pending[lane]) RT_HIP(ctx, hipStreamWaitEvent(render_stream, ctx->resolve_done[lane], 0));
-    if (ctx->prep_pending) RT_HIP(ctx, hipStreamWaitEvent(render_stream, ctx->prep_done, 0));
+    if (ctx->resolve_pending[lane]) RT_HIP(ctx, hipStreamWaitEvent(render_stream, ctx->ev_resolved[ctx->resolve_slot[lane]], 0));
+    if (ctx->prep_pending && ctx->prep_seen[lane] != ctx->prep_generation) {
+      RT_HIP(ctx, hipStreamWaitEvent(render_stream, ctx->prep_done, 0));
+      ctx->prep_seen[lane] = ctx->prep_generation;
+    }
   }
   RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], render_stream));
   LaunchConfig lc{};
   lc.variant = ctx->variant;
   lc.refill_min = ctx->refill_min < 1 ? 1 : (ctx->refill_min > 64 ? 64 : ctx->refill_min);
   int per_cu = ctx->blocks_per_cu;
-  if (per_cu <= 0) per_cu = persistent_blocks_per_cu(static_cast<size_t>(ctx->scene.image_records) * sizeof(float4));
+  if (per_cu <= 0 && ctx->variant == 2) {  // only the resident-wave shape sizes its grid by occupancy
+    if (ctx->occupancy_records != ctx->scene.image_records) {
+      ctx->occupancy_blocks = persistent_blocks_per_cu(static_cast<size_t>(ctx->scene.image_records) * sizeof(float4));
+      ctx->occupancy_records = ctx->scene.image_records;
+    }
+    per_cu = ctx->occupancy_blocks;
+  }
   if (per_cu <= 0) per_cu = 4;
   lc.persistent_blocks = per_cu * ctx->cu_count;
   lc.tile_chunk = ctx->tile_chunk;
@@ -1095,17 +1105,15 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   const int lrc = launch_render(ctx->scene, fp, lc, render_stream, &variant_used, &stage_used);
   if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
   RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], render_stream));
-  if (pipelined) {  // the main stream joins the renders in frame order: everything after this point sees frame k done
-    RT_HIP(ctx, hipEventRecord(ctx->render_done[lane], render_stream));
-    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->render_done[lane], 0));
-  }
+  if (pipelined)  // the main stream joins the renders in frame order: everything after this point sees frame k done
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_stop[slot], 0));
   RT_HIP(ctx, hipEventRecord(ctx->rnd_last_use[rnd], ctx->stream));
   ctx->rnd_used[rnd] = true;
   rnd_lock.unlock();
   if (staging != nullptr && launch_resolve(rp, ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "resolve launch failed");
   RT_HIP(ctx, hipEventRecord(ctx->ev_resolved[slot], ctx->stream));
-  if (pipelined) {
-    RT_HIP(ctx, hipEventRecord(ctx->resolve_done[lane], ctx->stream));
+  if (pipelined) {  // the lane's sample buffer is free again once this launch's resolve has run
+    ctx->resolve_slot[lane] = slot;
     ctx->resolve_pending[lane] = true;
     ctx->pipe_frames += 1;
   }
