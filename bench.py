@@ -79,6 +79,8 @@ def main():
                          "so that a launch carries eight frames' worth of tiles whatever the partition")
     ap.add_argument("--strip-rows", type=int, default=8)
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo = 1-GPU rehearsal via host)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="rehearsal on one GPU: run the N = 1 job through a one-rank communicator (rt_comm_init), as N > 1 does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the one-frame-per-launch and 80-slot legs (profiling)")
     ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_S, help="minimum timed window of a leg")
@@ -135,6 +137,10 @@ def main():
 
     tiles = None
     gather_path = None
+    if world == 1 and args.force_comm:
+        from rsraytracingv3_amd.distributed import TileParallelRenderer
+        gather_path = "rt_comm_init: one-rank communicator (rehearsal)"
+        tiles = TileParallelRenderer(dev, W, H, args.strip_rows)
     if world > 1:
         from rsraytracingv3_amd.distributed import TileParallelRenderer, TorchTileRenderer
         # production: the gather inside librt355 over RCCL; a gloo rehearsal (ranks sharing one GPU, which RCCL
@@ -279,6 +285,31 @@ def main():
             conn.update_buffers((W, H), scene, (0.0, 0.0))
             dev.sync()
 
+    # ---- N > 1: the assembled frame must be the single-GPU frame, bit for bit (per-pixel results do not depend on
+    # the partition) — one frame through the communicator, then the same frame on rank 0 alone -------------------
+    gather_check = None
+    if tiles is not None and type(tiles).__name__ == "TileParallelRenderer":
+        fence()
+        probe = (0.125, -0.25)
+        tiles.render(conn, probe, 0)
+        assembled = tiles.finish(read=True)
+        fence()
+        tiles.close()  # every rank leaves the communicator; rank 0 now owns the whole frame
+        tiles = None
+        if rank == 0:
+            try:
+                conn.frame_data.jitter, conn.frame_data.progressive_count = probe, 0
+                conn.draw()
+                dev.sync()
+                alone = target.read_rgba8()
+                same = bool(alone.shape == assembled.shape and np.array_equal(alone, assembled))
+                gather_check = {"assembled_frame_equals_single_gpu_frame": same,
+                                "differing_texels": int((alone != assembled).any(-1).sum()) if alone.shape == assembled.shape else -1}
+            except Exception as exc:  # the check must never cost the measurement
+                gather_check = {"error": str(exc)}
+        if world > 1:
+            dist.barrier()
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -335,6 +366,7 @@ def main():
             "partition": "row strips of %d, round-robin over %d GPU(s)%s" % (
                 args.strip_rows, world, ", strips gathered on rank 0 after every launch, beside the next one" if world > 1 else ""),
             "gather": gather_path,
+            "gather_check": gather_check,
             "headline_mode": "%d consecutive frames of the accumulation per launch (8 per GPU), one gather per launch; the "
                              "one_frame_per_launch leg is the per-frame figure (one launch and one gather per frame)" % B,
             "kernel_variant": args.variant,
