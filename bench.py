@@ -40,13 +40,17 @@ VALU_PEAK_TFLOPS = 157.3    # FP32 vector peak
 SIMDS = 1024                # 256 CUs x 4
 CLOCK_WARMUP_S = 2.0
 MIN_TIMED_S = 1.0
-KERNEL_NAMES = {0: "render_tiles", 1: "render_tiles<0>", 2: "render_persistent", 3: "render_blocks<4>"}
+KERNEL_NAMES = {0: "render_tiles", 1: "render_tiles<0>", 2: "render_persistent", 3: "render_blocks"}
 
 
 def kernel_name(st):
     """The render kernel the last launch used, from rt_stats (launch shape + what it staged into LDS)."""
     v = int(st.last_variant)
-    return "render_tiles<%d>%s" % (st.last_stage, " (sphere grid)" if st.last_stage == 3 else "") if v == 0 else KERNEL_NAMES.get(v, "?")
+    if v == 0:
+        return "render_tiles<%d>%s" % (st.last_stage, " (sphere grid)" if st.last_stage == 3 else "")
+    if v == 3:
+        return "render_blocks<%d, %d>" % (st.last_stage // 10, st.last_stage % 10)
+    return KERNEL_NAMES.get(v, "?")
 
 
 def algorithmic_bytes(pixels, segments, rough):

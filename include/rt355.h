@@ -72,8 +72,10 @@ typedef struct rt_stats {
                                     full scan in the last frame (must be 0)                    */
   float last_resolve_ms;      /* HIP-event time of the last launch's history-resolve pass (n_frames > 1) */
   uint32_t last_variant;      /* launch shape the last launch used (RT_OPT_VARIANT values 0..3)       */
-  uint32_t last_stage;        /* what that launch staged into LDS: 0 nothing, 1 sphere records, 2 the whole scene
-                                 image, 3 sphere records + the sphere grid (secondary rays walk the grid)   */
+  uint32_t last_stage;        /* render_tiles (variant 0/1): what that launch staged into LDS: 0 nothing, 1 sphere
+                                 records, 2 the whole scene image, 3 sphere records + the sphere grid (secondary rays
+                                 walk the grid); render_blocks (variant 3): 10 * waves per workgroup + waves per SIMD
+                                 its registers are budgeted for (26 multi-frame launches, 25 single frames)   */
   uint32_t grid_cells, grid_items; /* the current scene's sphere grid (0 = none: small scene, or not buildable) */
 } rt_stats;
 

@@ -30,8 +30,11 @@ namespace {
 #ifndef RT_PERSISTENT_WAVES
 #define RT_PERSISTENT_WAVES 6  // waves per SIMD the persistent kernel's register budget is held to
 #endif
-#ifndef RT_BLOCKS_WAVES
-#define RT_BLOCKS_WAVES 6
+#ifndef RT_BLOCKS_WAVES_BATCH
+#define RT_BLOCKS_WAVES_BATCH 6   // waves per SIMD the re-packing shape is budgeted for in multi-frame launches (80 VGPRs)
+#endif
+#ifndef RT_BLOCKS_WAVES_SINGLE
+#define RT_BLOCKS_WAVES_SINGLE 5  // ... and in single-frame launches, several of which are in flight (96 VGPRs, no spills)
 #endif
 #ifndef RT_X2_PREFETCH
 #define RT_X2_PREFETCH 1  // request the second random() texel during the scan (0: when the hit turns out rough)
@@ -42,8 +45,19 @@ namespace {
 #endif
 constexpr int kBlock = 256;
 constexpr int kTile = 8;  // 8x8 pixels per tile / wave
+#ifndef RT_BLOCK_NW
+#define RT_BLOCK_NW 2  // waves (8x8 tiles) per workgroup of the re-packing shape.  A/B on one device, headline / one
+                       // frame per launch in Grays/s: 4 waves 31.8 / 32.0, 2 waves 33.4 / 30.8 at 6 waves per SIMD and
+                       // 32.5 / 33.1 at 5, 1 wave 32.7 / 30.5, 8 waves 27.0 / 27.5 — hence 2 waves, and the register
+                       // budget by launch kind
+#endif
+#ifndef RT_XCD_REMAP
+#define RT_XCD_REMAP 0  // 1 = every XCD gets a contiguous run of tiles (neighbouring tiles share output lines).  A/B on one
+                        // device: headline -0.3 %, one frame per launch -10 % (a contiguous eighth of a frame is all sky or all
+                        // spheres: the XCDs finish at different times) — off
+#endif
 #ifndef RT_XCHG_PATHS
-#define RT_XCHG_PATHS 192  // re-packing needs the paths to fit 3 waves or fewer
+#define RT_XCHG_PATHS ((RT_BLOCK_NW - 1) * 64)  // re-packing needs the paths to fit one wave fewer
 #endif
 constexpr uint32_t kXchgPaths = RT_XCHG_PATHS;  // paths the block kernel's LDS exchange buffer holds
 
@@ -755,8 +769,8 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
 // registers and wave slots go to the next workgroup.  Path lengths vary 1..R, so without this most
 // of a tile's later scans run with a handful of live lanes.  Pixel results do not depend on which
 // lane finishes a path, so the frame stays bit-identical.
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(DeviceScene sc, FrameParams fp) {
+template <int NW, int WAVES>
+__global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_all[];
   // Live-path counts of the waves, double-buffered by iteration parity: iteration k writes and reads
   // wave_count[k & 1].  A wave reaches its write of iteration k+2 (same buffer) only after the count
@@ -770,7 +784,15 @@ __global__ void __launch_bounds__(NW * 64, RT_BLOCKS_WAVES) render_blocks(Device
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-  const uint32_t tile = blockIdx.x * NW + wave;
+#if RT_XCD_REMAP
+  // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one): give every XCD a contiguous run of
+  // tiles, so that neighbouring tiles — whose rows share 128-byte lines of the outputs — meet in one L2
+  const uint32_t nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u;
+  const uint32_t block = (xcd < xr ? xcd * (xq + 1u) : xr * (xq + 1u) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+#else
+  const uint32_t block = blockIdx.x;
+#endif
+  const uint32_t tile = block * NW + wave;
   const TilePos tp = tile_pos(fp, tile, tiles_x);
   const uint32_t x = tp.col * kTile + (lane & 7u);
   const uint32_t lrow = tp.row * kTile + (lane >> 3);
@@ -1177,12 +1199,12 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   const bool image_fits = sc.image_records <= kImageLdsRecords;  // whole scene image in LDS (<= 16 KB)
   int variant = lc.variant;
   if (variant < 0) {
-    // Measured on MI355X.  Re-packing a workgroup's surviving paths pays once a frame
-    // fills the chip more than once and the scan is short enough for the per-bounce barrier to matter
-    // little; scenes with hundreds of spheres and small frames (a rank's share of a tile-split frame)
-    // are fastest as plain tiles.  The resident-wave shape (2) is never the fastest since the
-    // primary-ray culling, which it cannot use; it stays selectable.
-    variant = (sc.n_sph_pad > 128u || tiles < 24000ull || sc.grid.enabled) ? 0 : 3;
+    // Measured on MI355X (tools/variant_sweep.py): the re-packing shape wins every multi-frame
+    // launch down to a rank's eighth of a 1080p frame, and single-frame launches from about half a 1080p frame up;
+    // scenes with hundreds of spheres (grid or not) and small single frames are fastest as plain tiles.  The
+    // resident-wave shape (2) is never the fastest since the primary-ray culling, which it cannot use; selectable.
+    const uint64_t enough = fp.batch > 1u ? 20000ull : 12000ull;
+    variant = (sc.n_sph_pad > 128u || tiles < enough || sc.grid.enabled) ? 0 : 3;
   }
   // the packed path state keeps 6 bits of bounce count and 26 bits of pixel index
   if (variant == 3 && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26))) variant = 0;
@@ -1201,9 +1223,15 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     hipLaunchKernelGGL(render_persistent, dim3(blocks), dim3(kBlock), lds_image, stream, sc, fp,
                        static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 3) {
-    const uint32_t blocks = static_cast<uint32_t>((tiles + 3) / 4);
+    const uint32_t blocks = static_cast<uint32_t>((tiles + RT_BLOCK_NW - 1) / RT_BLOCK_NW);
     const size_t bytes = lds_image + static_cast<size_t>(kXchgPaths) * 4 * sizeof(float4);
-    hipLaunchKernelGGL(render_blocks<4>, dim3(blocks), dim3(256), bytes, stream, sc, fp);
+    if (fp.batch > 1u) {
+      if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
+      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+    } else {
+      if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
+      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+    }
   } else {
     const uint32_t blocks = static_cast<uint32_t>((tiles + (kBlock / 64) - 1) / (kBlock / 64));
     if (stage_used) *stage_used = variant == 1 ? 0 : ((sc.grid.enabled && !(lc.flags & 2)) ? 3 : (image_fits ? 2 : 1));
