@@ -44,6 +44,10 @@ namespace {
                                // device: deferring costs these shapes 4 %, it pays only in render_tiles)
 #endif
 constexpr int kBlock = 256;
+#ifndef RT_TILES_BLOCK
+#define RT_TILES_BLOCK 256
+#endif
+constexpr int kTileBlock = RT_TILES_BLOCK;  // threads per workgroup of render_tiles (independent waves sharing the staged scene)
 constexpr int kTile = 8;  // 8x8 pixels per tile / wave
 #ifndef RT_BLOCK_NW
 #define RT_BLOCK_NW 2  // waves (8x8 tiles) per workgroup of the re-packing shape.  A/B on one device, headline / one
@@ -710,15 +714,18 @@ __device__ __forceinline__ TilePos tile_pos(const FrameParams &fp, uint32_t tile
 // STAGE: 2 = the whole scene image staged into LDS, 1 = only the sphere records (scenes of hundreds of
 // spheres), 3 = the sphere records and the sphere grid (secondary rays walk the grid), 0 = nothing (scenes
 // beyond a workgroup's LDS): everything else is read from global memory.
-template <int STAGE>
-__global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FrameParams fp) {
+// THREADS: 256, or 128 where the staged data is small enough for 128-thread workgroups to fill a CU's wave slots
+// (a workgroup holds its LDS until its slowest wave ends: smaller groups drain faster — +10 % at 256 spheres —
+// but at 1 024 spheres 28 KB per group would leave a CU with 10 waves instead of 20).
+template <int STAGE, int THREADS = kTileBlock>
+__global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_image[];
   if (STAGE != 0) {
     const uint32_t n = STAGE == 2 ? sc.image_records : sc.n_sph_pad;
-    for (uint32_t i = threadIdx.x; i < n; i += kBlock) lds_image[i] = sc.image[i];
+    for (uint32_t i = threadIdx.x; i < n; i += THREADS) lds_image[i] = sc.image[i];
     if (STAGE == 3) {  // the grid's cell table and item list, straight behind the sphere records
       const uint32_t m = (sc.grid.off_items - sc.grid.off_cells) + (sc.grid.n_items * 2u + 15u) / 16u;  // records
-      for (uint32_t i = threadIdx.x; i < m; i += kBlock) lds_image[sc.n_sph_pad + i] = sc.image[sc.grid.off_cells + i];
+      for (uint32_t i = threadIdx.x; i < m; i += THREADS) lds_image[sc.n_sph_pad + i] = sc.image[sc.grid.off_cells + i];
     }
     __syncthreads();
   }
@@ -729,7 +736,7 @@ __global__ void __launch_bounds__(kBlock) render_tiles(DeviceScene sc, FramePara
   }
   RT_PH_DECL
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const uint32_t wave = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
   const TilePos tp = tile_pos(fp, wave, tiles_x);
   const uint32_t x = tp.col * kTile + (lane & 7u);
@@ -1233,18 +1240,23 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
       hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
     }
   } else {
-    const uint32_t blocks = static_cast<uint32_t>((tiles + (kBlock / 64) - 1) / (kBlock / 64));
+    const uint32_t blocks = static_cast<uint32_t>((tiles + (kTileBlock / 64) - 1) / (kTileBlock / 64));
     if (stage_used) *stage_used = variant == 1 ? 0 : ((sc.grid.enabled && !(lc.flags & 2)) ? 3 : (image_fits ? 2 : 1));
     if (variant == 1) {
-      hipLaunchKernelGGL(render_tiles<0>, dim3(blocks), dim3(kBlock), 0, stream, sc, fp);
+      hipLaunchKernelGGL(render_tiles<0>, dim3(blocks), dim3(kTileBlock), 0, stream, sc, fp);
     } else if (sc.grid.enabled && !(lc.flags & 2)) {  // RT_OPT_FLAGS bit 1: ignore the grid (A/B)
       const size_t bytes = lds_sph + (static_cast<size_t>(sc.grid.off_items - sc.grid.off_cells) +
                                       (static_cast<size_t>(sc.grid.n_items) * 2 + 15) / 16) * sizeof(float4);
-      hipLaunchKernelGGL(render_tiles<3>, dim3(blocks), dim3(kBlock), bytes, stream, sc, fp);
+      if (bytes <= 12u * 1024u) {
+        const uint32_t blocks128 = static_cast<uint32_t>((tiles + 1) / 2);
+        hipLaunchKernelGGL((render_tiles<3, 128>), dim3(blocks128), dim3(128), bytes, stream, sc, fp);
+      } else {
+        hipLaunchKernelGGL((render_tiles<3, kTileBlock>), dim3(blocks), dim3(kTileBlock), bytes, stream, sc, fp);
+      }
     } else if (image_fits) {
-      hipLaunchKernelGGL(render_tiles<2>, dim3(blocks), dim3(kBlock), lds_image, stream, sc, fp);
+      hipLaunchKernelGGL(render_tiles<2>, dim3(blocks), dim3(kTileBlock), lds_image, stream, sc, fp);
     } else {
-      hipLaunchKernelGGL(render_tiles<1>, dim3(blocks), dim3(kBlock), lds_sph, stream, sc, fp);
+      hipLaunchKernelGGL(render_tiles<1>, dim3(blocks), dim3(kTileBlock), lds_sph, stream, sc, fp);
     }
   }
   return static_cast<int>(hipGetLastError());
