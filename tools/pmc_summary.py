@@ -37,7 +37,7 @@ for d in args.dirs:
             for key, pat in KERNELS.items():
                 if pat in r["Kernel_Name"]:
                     acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    m = re.search(r"(render_\w+(?:<\d+>)?|resolve_batch_kernel)", r["Kernel_Name"])
+                    m = re.search(r"(render_\w+(?:<[\d, ]+>)?|resolve_batch_kernel)", r["Kernel_Name"])
                     names[key].add(m.group(1) if m else r["Kernel_Name"])
         for key in KERNELS:
             # launches of the warm-up may carry fewer frames; keep the modal half (the timed launches) by median
