@@ -12,7 +12,7 @@ Protocol: an untimed clock warm-up of >= 2 s of back-to-back la
 MAX over ranks — is repeated until >= 1 s has been measured and the MEDIAN block is reported
 (`steps`, `ms_per_step` keep their meaning: ms_per_step = median block / steps).
 
-`value` is the headline leg: 8 frames per launch per GPU (rt_render_frames).  The same JSON line always
+`value` is the headline leg: 8 frames per launch per GPU (rt_render_frames; up to 16 where that divides --steps).  The same JSON line always
 carries, under `config`, the one-frame-per-launch leg (the reference's call pattern: one draw per loop turn)
 and the reference-exact 80-slot leg (15 zero-padded objects scanned as the reference's shader does).
 
@@ -259,7 +259,15 @@ def main():
                 "dt_min": float(dts.min()), "dt_max": float(dts.max()), "measured_s": float(dts.sum())}
 
     # ---- headline leg: B frames per launch ------------------------------------------------------------------
-    B = args.batch if args.batch > 0 else min(64, 8 * world)
+    # frames per launch: 8 per GPU of the job — or the next count up to 16 per GPU that divides --steps, so that a block
+    # of --steps frames has no ragged last launch (--steps 20: 10 frames per launch instead of 8 + 8 + 4)
+    B = args.batch
+    if B <= 0:
+        B = min(64, 8 * world)
+        for per_gpu in range(8, 17):
+            if per_gpu * world <= 64 and args.steps % (per_gpu * world) == 0:
+                B = per_gpu * world
+                break
     head = reduce_leg(timed_leg(B, args.steps, args.warmup, args.min_seconds, args.clock_warmup))
 
     # ---- extra legs: one frame per launch (reference call pattern); 80 zero-padded slots ------------------
@@ -332,8 +340,7 @@ def main():
     # Measured HBM traffic and issue utilisation come from the committed PMC passes of THIS workload and launch
     # shape (profiles/traffic_r02.json, collected by tools/profile_round.sh); for any other workload they are null.
     traffic = traffic_resolve = issue_util = None
-    workload_key = {"width": W, "height": H, "objects": n_objects, "bounces": args.bounces, "sky_width": args.sky,
-                    "frames_per_launch": B, "n_gpus": world}
+    workload_key = {"width": W, "height": H, "objects": n_objects, "bounces": args.bounces, "sky_width": args.sky, "n_gpus": world}
     for name in ("traffic_r02.json",):
         tpath = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tpath):
@@ -343,7 +350,9 @@ def main():
                 prof = json.load(f)
         except Exception:
             continue
-        if prof.get("workload_key") == workload_key:
+        prof_key = dict(prof.get("workload_key", {}))
+        prof_key.pop("frames_per_launch", None)  # the profile's launches carried 8 frames; traffic is taken per frame
+        if prof_key == workload_key and B > 1:
             # per launch of THIS run: the profile's bytes per frame x the frames an average launch of the block carried
             frames_per_launch = float(steps) / launches
             per_frame = prof.get("render_kernel", {}).get("hbm_bytes_per_frame")
@@ -371,8 +380,8 @@ def main():
                 args.strip_rows, world, ", strips gathered on rank 0 after every launch, beside the next one" if world > 1 else ""),
             "gather": gather_path,
             "gather_check": gather_check,
-            "headline_mode": "%d consecutive frames of the accumulation per launch (8 per GPU), one gather per launch; the "
-                             "one_frame_per_launch leg is the per-frame figure (one launch and one gather per frame)" % B,
+            "headline_mode": "%d consecutive frames of the accumulation per launch (%d per GPU), one gather per launch; the "
+                             "one_frame_per_launch leg is the per-frame figure (one launch and one gather per frame)" % (B, B // world),
             "kernel_variant": args.variant,
             "frames_per_launch": B,
             "progressive_count": "frame index k (1-spp frames of a resting camera accumulate, app.rs:208-254)",
