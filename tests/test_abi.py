@@ -80,3 +80,23 @@ def test_one_hip_runtime_whatever_the_import_order():
         out = subprocess.run([sys.executable, "-c", code % (root, order)], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-1500:]
         assert out.stdout.split()[0] == "1", "%s -> %s" % (order, out.stdout)
+
+
+def test_rust_binding_sketch_matches_the_header():
+    """INTEGRATION.md's `extern "C"` block cannot be compiled here (no Rust toolchain); at least every function it
+    declares must exist in include/rt355.h with the same number of parameters."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    header = open(os.path.join(root, "include", "rt355.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    c_params = {}
+    for m in re.finditer(r"RT355_API\s+[\w\s\*]+?\b(rt_\w+)\s*\(([^)]*)\)\s*;", header):
+        args = m.group(2).strip()
+        c_params[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    rust = re.findall(r"fn (rt_\w+)\(([^)]*)\)\s*->", text)
+    assert len(rust) >= 15
+    for name, args in rust:
+        assert name in c_params, "%s is not in the header" % name
+        n = 0 if not args.strip() else args.count(":")
+        assert n == c_params[name], "%s: %d parameters in the Rust sketch, %d in the header" % (name, n, c_params[name])
