@@ -509,10 +509,13 @@ __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, ui
 // loop goes on.
 // DEFER_SKY: on a miss only mark the path; its skybox texel is fetched in path_end, together with the other
 // finished lanes of the wave instead of a few lanes at a time after every bounce.
-template <bool DEFER_SKY>
+// LEAN: the launch writes float samples only (multi-frame launches and the single-frame launches in flight: no
+// per-frame diagnostic outputs, no history, the sRGB store happens in resolve_batch_kernel) — the kernel is
+// compiled without those paths.
+template <bool DEFER_SKY, bool LEAN = false>
 __device__ __forceinline__ bool path_shade(const SceneView &sv, const FrameParams &fp, Path &s, const Hit h,
                                            const float x1, const float x2, const float seed1) {
-  if (fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
+  if (!LEAN && fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
   s.seg += 1;
   if (h.obj < 0) {  // frag.hlsl:14-17: miss -> skybox, energy 0, loop ends (|0| < EPSILON)
     if (DEFER_SKY) {
@@ -566,7 +569,7 @@ __device__ __forceinline__ bool path_shade(const SceneView &sv, const FrameParam
 // lane carries a ray).  The first random() texel is requested before the scan and used after it if the hit is
 // rough: the gather's latency (an L2 round trip) hides under the object scan.  Picks the
 // wave-cooperative scan when at most 32 lanes are live.  Returns the lane's new `alive`.
-template <bool DEFER_SKY, bool GRID = false>
+template <bool DEFER_SKY, bool GRID = false, bool LEAN = false>
 __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameParams &fp, Path &s, bool alive,
                                                const unsigned long long *__restrict__ primary_mask,
                                                const unsigned long long *__restrict__ primary_mask2 RT_PH_PARAMS,
@@ -591,12 +594,12 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
   if (primary_mask != nullptr) {  // wave-uniform: all live lanes carry primary rays of one tile
     if (alive) {
       const SphereHit sh = scan_spheres_listed(sv.sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
-      if (fp.cull_check) {  // self-check build of the frame: the full scan must agree
+      if (!LEAN && fp.cull_check) {  // self-check frame: the full scan must agree
         const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
         if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
       }
       RT_REQUEST_X2
-      alive = path_shade<DEFER_SKY>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+      alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     }
     RT_PH_MARK(0)
   } else if (GRID) {
@@ -608,19 +611,19 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
                       (fabsf(dot3(s.d, s.d) - 1.0f) <= 4e-6f);  // unit direction (not after a non-unit plane normal)
     if (near) sh = scan_grid(sv, *gp, s.o, s.d);
     if (alive & !near) sh = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
-    if (fp.cull_check && near) {  // self-check frame: the linear scan must agree
+    if (!LEAN && fp.cull_check && near) {  // self-check frame: the linear scan must agree
       const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
       if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
     }
     RT_PH_MARK(1)
     RT_REQUEST_X2
-    if (alive) alive = path_shade<DEFER_SKY>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+    if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     RT_PH_MARK(3)
   } else if (n_live <= 32u) {
     const SphereHit sh = scan_spheres_coop(sv.sph, sv.n_sph_pad, s.o, s.d, alive, live, n_live);
     RT_PH_MARK(2)
     RT_REQUEST_X2
-    if (alive) alive = path_shade<DEFER_SKY>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+    if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     RT_PH_MARK(3)
   } else {
     if (alive) {
@@ -630,7 +633,7 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
       RT_REQUEST_X2
       sh = scan_spheres(sv.sph, half, n, s.o, s.d, sh);
       RT_PH_MARK(1)
-      alive = path_shade<DEFER_SKY>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+      alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     }
     RT_PH_MARK(3)
   }
@@ -640,11 +643,17 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
 
 // frag.hlsl:60-65 + the Rgba8UnormSrgb store (D13).  At progressive_count 0 the history weight
 // is exactly 0, so the history is not read.
-template <bool DEFER_SKY = false>
+template <bool DEFER_SKY = false, bool LEAN = false>
 __device__ __forceinline__ void path_end(const FrameParams &fp, const Path &s) {
   const size_t p = s.p;
   f3 result = s.result;
   if (DEFER_SKY && (s.rough & 0x80000000u)) result = fma3(s.energy, sample_hdri(fp, s.d), result);  // frag.hlsl:14-17, D1
+  if (LEAN) {  // opacity 1, no history: fma(result, 1, 0 * 0) is result itself; the sample goes to the staging buffer
+    fp.rgbf32[3 * p] = result.x;
+    fp.rgbf32[3 * p + 1] = result.y;
+    fp.rgbf32[3 * p + 2] = result.z;
+    return;
+  }
   f3 prev = mk3(0.0f, 0.0f, 0.0f);
   if (fp.progressive_count != 0u) {
     if (fp.accum_mode == 1) {
@@ -776,7 +785,7 @@ __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FramePar
 // registers and wave slots go to the next workgroup.  Path lengths vary 1..R, so without this most
 // of a tile's later scans run with a handful of live lanes.  Pixel results do not depend on which
 // lane finishes a path, so the frame stays bit-identical.
-template <int NW, int WAVES>
+template <int NW, int WAVES, bool LEAN>
 __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_all[];
   // Live-path counts of the waves, double-buffered by iteration parity: iteration k writes and reads
@@ -814,7 +823,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   if ((x < fp.width) & (lrow < fp.local_rows) & (tp.frame < fp.batch)) {
     path_begin(fp, x, lrow, tp.frame, s);
     alive = fp.reflection_limit != 0u;
-    if (!alive) path_end<RT_DEFER_SKY_BLOCKS>(fp, s);
+    if (!alive) path_end<RT_DEFER_SKY_BLOCKS, LEAN>(fp, s);
   }
   uint32_t live_waves = NW;
   RT_PH_DECL
@@ -831,7 +840,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   for (;;) {
     {
       const bool was = alive;
-      alive = path_step_wave<RT_DEFER_SKY_BLOCKS>(sv, fp, s, alive, primary_mask, primary_mask2 RT_PH_ARGS);
+      alive = path_step_wave<RT_DEFER_SKY_BLOCKS, false, LEAN>(sv, fp, s, alive, primary_mask, primary_mask2 RT_PH_ARGS);
       primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
       rough_total += s.rough & 0x7fffffffu;
       s.rough &= 0x80000000u;  // keeps "ended on a miss" (the skybox is sampled in path_end)
@@ -864,7 +873,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
         q[3] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p | (s.seg << 26)));
       }
       if (finished) {  // the lane's registers are about to change hands
-        path_end<RT_DEFER_SKY_BLOCKS>(fp, s);
+        path_end<RT_DEFER_SKY_BLOCKS, LEAN>(fp, s);
         seg_total += s.seg;
         finished = false;
       }
@@ -893,7 +902,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   }
   RT_PH_MARK(5)
   if (finished) {
-    path_end<RT_DEFER_SKY_BLOCKS>(fp, s);
+    path_end<RT_DEFER_SKY_BLOCKS, LEAN>(fp, s);
     seg_total += s.seg;
   }
   RT_PH_MARK(6)
@@ -1232,12 +1241,18 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   } else if (variant == 3) {
     const uint32_t blocks = static_cast<uint32_t>((tiles + RT_BLOCK_NW - 1) / RT_BLOCK_NW);
     const size_t bytes = lds_image + static_cast<size_t>(kXchgPaths) * 4 * sizeof(float4);
-    if (fp.batch > 1u) {
+    // sample-only launches (the staging buffer is the only output): multi-frame launches and pipelined single frames
+    const bool lean = fp.rgba8 == nullptr && fp.rgbf32 != nullptr && fp.hist_f32 == nullptr && fp.segments == nullptr &&
+                      fp.hits == nullptr && fp.progressive_count == 0u && fp.opacity == 1.0f && fp.keep == 0.0f && !fp.cull_check;
+    if (fp.batch > 1u && lean) {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
-      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+    } else if (lean) {
+      if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
+      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
     } else {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
-      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, false>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
     }
   } else {
     const uint32_t blocks = static_cast<uint32_t>((tiles + (kTileBlock / 64) - 1) / (kTileBlock / 64));
