@@ -229,6 +229,10 @@ RT355_API int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segmen
 /* HIP-event times of the history-resolve pass that follows the render kernel of a multi-frame launch
  * (rt_render_frames), most recent n launches, oldest first; ~0 for single-frame launches. */
 RT355_API int rt_get_resolve_history(rt_context *ctx, uint32_t n, float *resolve_ms);
+/* HIP-event time from the start of the oldest to the end of the newest render kernel of the most recent n launches:
+ * with several launches in flight (RT_OPT_INFLIGHT, RT_OPT_BATCH_INFLIGHT) the kernel times of rt_get_frame_history
+ * overlap and their sum counts the device more than once; this span does not. */
+RT355_API int rt_get_launch_span(rt_context *ctx, uint32_t n, float *span_ms);
 /* Order all of the context's work on a caller-owned hipStream_t (e.g. the stream an RCCL
  * gather is issued on).  The default is a private non-blocking stream. */
 RT355_API int rt_set_stream(rt_context *ctx, void *hip_stream);
@@ -258,9 +262,12 @@ enum {
                               (app.rs:208-254) and one 1080p frame leaves a fifth of the GPU idle during its
                               ramp-up and tail; the history is still updated strictly in frame order on the
                               context's stream.  1 = one launch at a time (kernel times do not overlap).     */
-  RT_OPT_GRID_MIN = 7      /* scenes with at least this many spheres (default 129) get a uniform grid at the next
+  RT_OPT_GRID_MIN = 7,     /* scenes with at least this many spheres (default 129) get a uniform grid at the next
                               rt_set_scene: secondary rays then test the spheres of the cells they cross instead of
                               every sphere (ray.hlsl:97-107 scans linearly; the reference caps scenes at 80)       */
+  RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8: as RT_OPT_INFLIGHT, each
+                              launch staging its samples in a buffer of its own; the history is updated in frame
+                              order on the context's stream.  1 = one launch at a time.                           */
 };
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */

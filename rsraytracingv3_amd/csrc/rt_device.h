@@ -19,6 +19,8 @@ constexpr uint32_t kTotalShards = 32;       // frame-total counters are sharded 
 constexpr uint32_t kTotalShardStride = 16;  // u64 words between shards (128 B)
 constexpr uint32_t kSphBatch = 8;  // sphere records consumed per scan-loop trip
 constexpr uint32_t kMaxBatch = 64;  // frames one launch can render (rt_render_frames)
+constexpr uint32_t kQueueShards = 32;  // path queue of the streamed shape: shards, each with its own head counters
+constexpr uint32_t kQueueHeadWords = 2 * kQueueShards * 32;  // u32 words of head counters per launch (128 B apart)
 
 // The compiled scene is ONE allocation of float4 records, laid out exactly as the kernels stage it into LDS
 // ("scene image"); n = n_sph_pad, p = n_pl:
@@ -106,6 +108,13 @@ struct FrameParams {
   const unsigned long long *tile_masks;
   uint32_t mask_words;
   int cull_check;
+  // Path queue of the streamed shape (variant 4): the primary pass appends the paths that go on after their first
+  // segment, the bounce pass consumes them.  64 B of path state per record as four float4 planes (plane k at
+  // queue + k * queue_plane), kQueueShards shards of queue_shard_cap records each; the shards' write heads are
+  // tile_counters[s * 32], their read heads tile_counters[(kQueueShards + s) * 32] (zero at launch).  null = no queue.
+  float4 *queue;
+  uint32_t queue_shard_cap;
+  size_t queue_plane;
 };
 
 // resolve_batch_kernel: folds a batch's float samples into the history, frame by frame
@@ -131,13 +140,21 @@ struct ResolveParams {
 // kernels (rt_kernels.hip)
 struct LaunchConfig {
   int variant;            // -1 auto; 0 tiles, LDS geometry; 1 tiles, global-memory geometry;
-                          // 2 resident waves with lane refill; 3 block-compacting tiles
+                          // 2 resident waves with lane refill; 3 block-compacting tiles;
+                          // 4 streamed: primary pass -> path queue -> resident waves refilled from the queue
   int refill_min;         // variant 2: idle lanes tolerated before a wave pulls new pixels
   int persistent_blocks;  // variant 2: grid size (resident workgroups)
-  int tile_chunk;         // variant 2: consecutive 8x8 tiles per counter increment
+  int tile_chunk;         // variant 2: consecutive 8x8 tiles per counter increment; variant 4: 64-path units a wave
+                          // takes off the queue per counter increment
+  int stream_blocks;      // variant 4: grid size of the bounce pass (resident workgroups)
   int flags;              // reserved for experiment switches
 };
 int persistent_blocks_per_cu(size_t lds_bytes);
+// The launch shape launch_render will use for this launch (the auto rule, and the fall-backs of a forced variant),
+// and what the streamed shape needs: records per queue shard for this launch's tiles, resident workgroups per CU.
+int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc);
+uint32_t stream_queue_shard_cap(const FrameParams &fp);
+int stream_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);
 int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream);
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream,

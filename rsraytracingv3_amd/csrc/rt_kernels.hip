@@ -921,6 +921,193 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   RT_PH_FLUSH(fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride)
 }
 
+// Streamed shape (variant 4), for launches of several frames that write float samples only.  Two kernels:
+//   primary_stream  one 8x8 tile per wave: the primary segment with the tile's culled sphere list, exactly as
+//                   render_blocks' first iteration; paths that end there are written out, the others are appended
+//                   to a path queue in global memory (64 B of state each, four float4 planes; one atomic per wave on
+//                   the write head of the workgroup's shard);
+//   bounce_stream   resident waves take chunks of paths off the queue and REFILL lanes whose path has ended from
+//                   it after every bounce, so scans run with full waves until the queue is dry — no per-bounce
+//                   barrier, no workgroup re-packing; waves synchronise once (scene image staged into LDS).
+// Pixel results do not depend on which lane carries a path, so the frame stays bit-identical.  Worth it when a
+// launch holds many paths per resident wave (multi-frame launches); a single 1080p frame has ~200.
+#ifndef RT_STREAM_NW1
+#define RT_STREAM_NW1 4  // waves (tiles) per workgroup of the primary pass
+#endif
+#ifndef RT_STREAM_NW2
+#define RT_STREAM_NW2 2  // waves per workgroup of the bounce pass (they share the staged scene image only)
+#endif
+#ifndef RT_STREAM_MIN_TILES
+#define RT_STREAM_MIN_TILES 0  // auto rule: sample-only launches of this many 8x8 tiles are streamed; 0 = never (A/B on one device,
+                               // 1080p, frames per launch 2 / 4 / 8 / 16: streamed 26.4 / 31.6 / 33.6 / 34.2 Grays/s against 30.4 /
+                               // 32.8 / 34.1 / 34.0 re-packed — full waves make the wave-wide square-root skip of the scan fire
+                               // rarely, which costs what the fuller lanes gain)
+#endif
+#ifndef RT_STREAM_WAVES
+#define RT_STREAM_WAVES 6  // waves per SIMD the bounce pass is budgeted for
+#endif
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) primary_stream(DeviceScene sc, FrameParams fp) {
+  extern __shared__ float4 lds_all[];
+  for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
+  const SceneView sv = make_view(sc, lds_all, lds_all);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
+  const uint32_t tile = blockIdx.x * NW + wave;
+  const TilePos tp = tile_pos(fp, tile, tiles_x);
+  const uint32_t x = tp.col * kTile + (lane & 7u);
+  const uint32_t lrow = tp.row * kTile + (lane >> 3);
+  Path s;
+  s.p = 0;
+  s.seg = 0;
+  s.rough = 0;
+  s.o = s.d = s.energy = s.result = mk3(0.0f, 0.0f, 0.0f);
+  s.rng = Rng{0.0f, 0.0f, 0.0f};
+  bool alive = false;
+  uint32_t seg_total = 0;
+  if ((x < fp.width) & (lrow < fp.local_rows) & (tp.frame < fp.batch)) {
+    path_begin(fp, x, lrow, tp.frame, s);
+    alive = fp.reflection_limit != 0u;
+    if (!alive) path_end<false, true>(fp, s);
+  }
+  RT_PH_DECL
+  __syncthreads();  // scene image staged
+  const unsigned long long *primary_mask =
+      fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words : nullptr;
+  const unsigned long long *primary_mask2 =
+      fp.tile_masks != nullptr ? fp.tile_masks + static_cast<size_t>(tiles_x + tp.row) * fp.mask_words : nullptr;
+  const bool was = alive;
+  alive = path_step_wave<false, false, true>(sv, fp, s, alive, primary_mask, primary_mask2 RT_PH_ARGS);
+  if (was & !alive) {
+    path_end<false, true>(fp, s);
+    seg_total = s.seg;
+  }
+  const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
+  if (live != 0ull) {  // wave-uniform
+    const uint32_t shard = blockIdx.x % kQueueShards;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&fp.tile_counters[shard * 32u], static_cast<uint32_t>(__popcll(live)));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (alive) {
+      const size_t r = static_cast<size_t>(shard) * fp.queue_shard_cap + base +
+                       __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+      float4 *q = fp.queue + r;
+      q[0] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
+      q[fp.queue_plane] = make_float4(s.d.y, s.d.z, s.energy.x, s.energy.y);
+      q[2 * fp.queue_plane] = make_float4(s.energy.z, s.result.x, s.result.y, s.result.z);
+      q[3 * fp.queue_plane] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p | (s.seg << 26)));
+    }
+  }
+  add_totals(fp, seg_total, s.rough & 0x7fffffffu, 0u);
+  RT_PH_FLUSH(fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride)
+}
+
+template <int NW, int WAVES>
+__global__ void __launch_bounds__(NW * 64, WAVES) bounce_stream(DeviceScene sc, FrameParams fp, uint32_t refill_min, uint32_t chunk) {
+  extern __shared__ float4 lds_all[];
+  for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
+  __syncthreads();
+  const SceneView sv = make_view(sc, lds_all, lds_all);
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  // Work distribution: a wave takes `chunk` consecutive records off the read head of a shard (one atomic), starting
+  // with the shard of its number and moving on when a shard is dry.  The write heads are final: the primary pass
+  // ran before this kernel on the same stream.
+  uint32_t shard = (blockIdx.x * NW + wave) % kQueueShards, shards_done = 0;
+  size_t q_pos = 0, q_end = 0;  // records of the chunk in hand [q_pos, q_end), absolute record numbers
+  Path s;
+  s.p = 0;
+  s.seg = 0;
+  s.rough = 0;
+  s.o = s.d = s.energy = s.result = mk3(0.0f, 0.0f, 0.0f);
+  s.rng = Rng{0.0f, 0.0f, 0.0f};
+  bool alive = false;
+  bool work_left = true;
+  uint32_t seg_total = 0, rough_total = 0, wave_iters = 0;
+  RT_PH_DECL
+  for (;;) {
+    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
+    const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
+    if (work_left && n_idle >= refill_min) {
+      unsigned long long need = idle;
+      while (need != 0ull) {
+        if (q_pos >= q_end) {  // next chunk
+          bool got = false;
+          while (shards_done < kQueueShards) {
+            const uint32_t filled = fp.tile_counters[shard * 32u];
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&fp.tile_counters[(kQueueShards + shard) * 32u], chunk);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t < filled) {
+              q_pos = static_cast<size_t>(shard) * fp.queue_shard_cap + t;
+              q_end = q_pos + min(chunk, filled - t);
+              got = true;
+              break;
+            }
+            shard = (shard + 1u) % kQueueShards;  // this shard is dry for good
+            shards_done += 1u;
+          }
+          if (!got) {
+            work_left = false;
+            break;
+          }
+        }
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(need >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(need), 0u));
+        const bool needy = (need >> lane) & 1ull;
+        const uint32_t n_need = static_cast<uint32_t>(__popcll(need));
+        const uint32_t room = static_cast<uint32_t>(q_end - q_pos);
+        const uint32_t taken = n_need < room ? n_need : room;
+        if (needy && below < taken) {
+          const float4 *q = fp.queue + q_pos + below;
+          const float4 a = q[0], b = q[fp.queue_plane], c = q[2 * fp.queue_plane], e = q[3 * fp.queue_plane];
+          s.o = mk3(a.x, a.y, a.z);
+          s.d = mk3(a.w, b.x, b.y);
+          s.energy = mk3(b.z, b.w, c.x);
+          s.result = mk3(c.y, c.z, c.w);
+          s.rng = Rng{e.x, e.y, e.z};
+          const uint32_t packed = __float_as_uint(e.w);
+          s.p = packed & 0x03ffffffu;
+          s.seg = packed >> 26;
+          s.rough = 0;
+          alive = true;
+        }
+        q_pos += taken;
+        need = __builtin_amdgcn_ballot_w64(needy && below >= taken);
+      }
+    }
+    RT_PH_MARK(5)
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {
+      if (!work_left) break;
+      continue;
+    }
+    wave_iters += 1u;
+    const bool was = alive;
+    alive = path_step_wave<false, false, true>(sv, fp, s, alive, nullptr, nullptr RT_PH_ARGS);
+    rough_total += s.rough & 0x7fffffffu;
+    s.rough = 0;
+    if (was & !alive) {
+      path_end<false, true>(fp, s);
+      seg_total += s.seg;
+    }
+    RT_PH_MARK(6)
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    seg_total += __shfl_xor(seg_total, off, 64);
+    rough_total += __shfl_xor(rough_total, off, 64);
+  }
+  if (lane == 0) {
+    unsigned long long *shard_totals = fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride;
+    if (seg_total) atomicAdd(&shard_totals[0], static_cast<unsigned long long>(seg_total));
+    if (rough_total) atomicAdd(&shard_totals[1], static_cast<unsigned long long>(rough_total));
+    if (wave_iters) atomicAdd(&shard_totals[2], static_cast<unsigned long long>(wave_iters));
+  }
+  RT_PH_FLUSH(fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride)
+}
+
 // Resident waves + lane refill.  `refill_min`: idle lanes a wave tolerates before it pulls
 // new pixels (1 = refill at once).  fp.tile_counters: 8 counters, 128 B apart, zero at launch.
 __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent(DeviceScene sc, FrameParams fp, uint32_t refill_min,
@@ -1202,6 +1389,52 @@ __global__ void sqrt_exhaustive_kernel(unsigned long long *mismatches) {
 
 }  // namespace
 
+namespace {
+// sample-only launches (the staging buffer is the only output): multi-frame launches and pipelined single frames
+bool sample_only(const FrameParams &fp) {
+  return fp.rgba8 == nullptr && fp.rgbf32 != nullptr && fp.hist_f32 == nullptr && fp.segments == nullptr && fp.hits == nullptr &&
+         fp.progressive_count == 0u && fp.opacity == 1.0f && fp.keep == 0.0f && !fp.cull_check;
+}
+uint64_t launch_tiles(const FrameParams &fp) {
+  const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
+  const uint32_t tiles_y = (fp.local_rows + kTile - 1) / kTile;
+  return static_cast<uint64_t>(tiles_x) * tiles_y * fp.batch;  // the batch as one stacked image
+}
+}  // namespace
+
+uint32_t stream_queue_shard_cap(const FrameParams &fp) {
+  const uint64_t blocks = (launch_tiles(fp) + RT_STREAM_NW1 - 1) / RT_STREAM_NW1;
+  return static_cast<uint32_t>((blocks + kQueueShards - 1) / kQueueShards) * RT_STREAM_NW1 * 64u;
+}
+
+int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc) {
+  const uint64_t tiles = launch_tiles(fp);
+  const size_t lds_sph = static_cast<size_t>(sc.n_sph_pad) * sizeof(float4);
+  const bool image_fits = sc.image_records <= kImageLdsRecords;  // whole scene image in LDS (<= 16 KB)
+  int variant = lc.variant;
+  if (variant < 0) {
+    // Measured on MI355X (tools/variant_sweep.py, DESIGN.md §5): the re-packing shape wins every multi-frame
+    // launch down to a rank's eighth of a 1080p frame, and single-frame launches from about half a 1080p frame up;
+    // scenes with hundreds of spheres (grid or not) and small single frames are fastest as plain tiles.  The
+    // resident-wave shape (2) is never the fastest since the primary-ray culling, which it cannot use; selectable.
+    // The streamed shape (4) only draws level from 16 frames per launch up; selectable.
+    const uint64_t enough = fp.batch > 1u ? 20000ull : 12000ull;
+    variant = (sc.n_sph_pad > 128u || tiles < enough || sc.grid.enabled) ? 0 : 3;
+#if RT_STREAM_MIN_TILES
+    if (variant == 3 && tiles >= RT_STREAM_MIN_TILES && sample_only(fp)) variant = 4;
+#endif
+  }
+  // the streamed shape writes float samples only and needs its queue
+  if (variant == 4 && !sample_only(fp)) variant = 3;
+  // the packed path state keeps 6 bits of bounce count and 26 bits of pixel index
+  if ((variant == 3 || variant == 4) && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26))) variant = 0;
+  // the re-packing, streamed and resident-wave shapes keep the whole scene image in LDS; bigger scenes render as tiles
+  if ((variant == 3 || variant == 2 || variant == 4) && !image_fits) variant = 0;
+  // tiles whose sphere records do not fit a workgroup's default 64 KB of LDS scan them from global memory
+  if (variant == 0 && !image_fits && lds_sph > 60u * 1024u) variant = 1;
+  return variant;
+}
+
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream, int *variant_used,
                   int *stage_used) {
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
@@ -1212,22 +1445,9 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   if (tiles * (kTile * kTile) > 0xffffffffull) return static_cast<int>(hipErrorInvalidValue);  // pixel indices are 32-bit
   const size_t lds_sph = static_cast<size_t>(sc.n_sph_pad) * sizeof(float4);
   const size_t lds_image = static_cast<size_t>(sc.image_records) * sizeof(float4);
-  const bool image_fits = sc.image_records <= kImageLdsRecords;  // whole scene image in LDS (<= 16 KB)
-  int variant = lc.variant;
-  if (variant < 0) {
-    // Measured on MI355X (tools/variant_sweep.py, DESIGN.md §5): the re-packing shape wins every multi-frame
-    // launch down to a rank's eighth of a 1080p frame, and single-frame launches from about half a 1080p frame up;
-    // scenes with hundreds of spheres (grid or not) and small single frames are fastest as plain tiles.  The
-    // resident-wave shape (2) is never the fastest since the primary-ray culling, which it cannot use; selectable.
-    const uint64_t enough = fp.batch > 1u ? 20000ull : 12000ull;
-    variant = (sc.n_sph_pad > 128u || tiles < enough || sc.grid.enabled) ? 0 : 3;
-  }
-  // the packed path state keeps 6 bits of bounce count and 26 bits of pixel index
-  if (variant == 3 && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26))) variant = 0;
-  // the re-packing and resident-wave shapes keep the whole scene image in LDS; bigger scenes render as tiles
-  if ((variant == 3 || variant == 2) && !image_fits) variant = 0;
-  // tiles whose sphere records do not fit a workgroup's default 64 KB of LDS scan them from global memory
-  if (variant == 0 && !image_fits && lds_sph > 60u * 1024u) variant = 1;
+  const bool image_fits = sc.image_records <= kImageLdsRecords;
+  int variant = pick_variant(sc, fp, lc);
+  if (variant == 4 && fp.queue == nullptr) variant = 3;  // no queue handed in: the re-packing shape serves
   if (variant_used) *variant_used = variant;
   if (stage_used) *stage_used = 2;  // the re-packing and resident-wave shapes stage the whole image
   if (variant == 2) {
@@ -1238,12 +1458,18 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     const uint32_t chunk = static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
     hipLaunchKernelGGL(render_persistent, dim3(blocks), dim3(kBlock), lds_image, stream, sc, fp,
                        static_cast<uint32_t>(lc.refill_min), chunk);
+  } else if (variant == 4) {
+    if (stage_used) *stage_used = 40;
+    const uint32_t blocks1 = static_cast<uint32_t>((tiles + RT_STREAM_NW1 - 1) / RT_STREAM_NW1);
+    hipLaunchKernelGGL((primary_stream<RT_STREAM_NW1>), dim3(blocks1), dim3(RT_STREAM_NW1 * 64), lds_image, stream, sc, fp);
+    uint32_t blocks2 = static_cast<uint32_t>(lc.stream_blocks < 1 ? 1 : lc.stream_blocks);
+    const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
+    hipLaunchKernelGGL((bounce_stream<RT_STREAM_NW2, RT_STREAM_WAVES>), dim3(blocks2), dim3(RT_STREAM_NW2 * 64), lds_image, stream, sc,
+                       fp, static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 3) {
     const uint32_t blocks = static_cast<uint32_t>((tiles + RT_BLOCK_NW - 1) / RT_BLOCK_NW);
     const size_t bytes = lds_image + static_cast<size_t>(kXchgPaths) * 4 * sizeof(float4);
-    // sample-only launches (the staging buffer is the only output): multi-frame launches and pipelined single frames
-    const bool lean = fp.rgba8 == nullptr && fp.rgbf32 != nullptr && fp.hist_f32 == nullptr && fp.segments == nullptr &&
-                      fp.hits == nullptr && fp.progressive_count == 0u && fp.opacity == 1.0f && fp.keep == 0.0f && !fp.cull_check;
+    const bool lean = sample_only(fp);
     if (fp.batch > 1u && lean) {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
       hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
@@ -1297,6 +1523,14 @@ int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned lon
   hipLaunchKernelGGL(cull_slabs_kernel, dim3((tiles_x + tiles_y + 3) / 4), dim3(256), 0, stream, sc, fp, masks, tiles_x,
                      tiles_y);
   return static_cast<int>(hipGetLastError());
+}
+
+int stream_blocks_per_cu(size_t lds_bytes) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bounce_stream<RT_STREAM_NW2, RT_STREAM_WAVES>, RT_STREAM_NW2 * 64, lds_bytes) !=
+      hipSuccess)
+    return 0;
+  return n;
 }
 
 int persistent_blocks_per_cu(size_t lds_bytes) {

@@ -32,7 +32,8 @@ struct rt_context {
   // ring ahead, so the most recent kRing/2 frames are always readable.
   static constexpr uint32_t kRing = 1024;
   static constexpr uint32_t kCounterWords = kTotalShards * kTotalShardStride;  // u64 words per ring slot
-  static constexpr uint32_t kTileWords = 8 * 32; // u32 words per ring slot: 8 shard counters, 128 B apart
+  static constexpr uint32_t kTileWords = kQueueHeadWords;  // u32 words per ring slot: variant 2's 8 work counters / variant 4's
+                                                          // 2 x kQueueShards queue heads, 128 B apart
   std::vector<hipEvent_t> ev_start, ev_stop, ev_resolved;  // render kernel = start..stop, resolve pass = stop..resolved
   bool timing_valid = false;
 
@@ -114,6 +115,7 @@ struct rt_context {
   uint32_t occupancy_records = ~0u;  // ... a scene image of this many records
   static constexpr int kMaxInflight = 8;
   int inflight = 4;
+  int batch_inflight = 2;  // RT_OPT_BATCH_INFLIGHT
   uint64_t prep_generation = 0;                 // bumped whenever prep_done is re-recorded
   uint64_t prep_seen[kMaxInflight] = {};        // generation each render stream has already waited for
   int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid
@@ -124,6 +126,11 @@ struct rt_context {
   bool prep_pending = false;                // work the renders depend on was queued on the main stream (prep_done)
   float *d_pipe_samples[kMaxInflight] = {};
   size_t pipe_cap[kMaxInflight] = {};  // in floats
+  // path queues of the streamed shape (variant 4): one per pipelined lane, the last one for multi-frame launches
+  float4 *d_queue[kMaxInflight + 1] = {};
+  size_t queue_cap[kMaxInflight + 1] = {};  // in float4 records (4 planes)
+  int stream_occupancy_blocks = 0;
+  uint32_t stream_occupancy_records = 0xffffffffu;
   uint64_t pipe_frames = 0;
   rt_stats stats{};
   std::string error;
@@ -375,10 +382,12 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_tile_counters);
   (void)hipFree(ctx->d_masks);
   (void)hipFree(ctx->d_samples);
+  (void)hipFree(ctx->d_queue[rt_context::kMaxInflight]);
   (void)hipFree(ctx->d_kept);
   for (int i = 0; i < rt_context::kMaxInflight; ++i) {
     if (ctx->render_stream[i]) (void)hipStreamSynchronize(ctx->render_stream[i]);
     (void)hipFree(ctx->d_pipe_samples[i]);
+    (void)hipFree(ctx->d_queue[i]);
     if (ctx->render_stream[i]) (void)hipStreamDestroy(ctx->render_stream[i]);
   }
   if (ctx->prep_done) (void)hipEventDestroy(ctx->prep_done);
@@ -798,7 +807,7 @@ int rt_set_option(rt_context *ctx, int option, int value) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   switch (option) {
     case RT_OPT_VARIANT:
-      if (value < -1 || value > 3) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", value);
+      if (value < -1 || value > 4) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", value);
       ctx->variant = value;
       return RT_OK;
     case RT_OPT_REFILL_MIN:
@@ -824,6 +833,11 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       if (value < 1 || value > rt_context::kMaxInflight)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_INFLIGHT takes 1..%d", rt_context::kMaxInflight);
       ctx->inflight = value;  // a frame already in flight keeps its lane: lanes are only re-used after their resolve
+      return RT_OK;
+    case RT_OPT_BATCH_INFLIGHT:
+      if (value < 1 || value > rt_context::kMaxInflight)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BATCH_INFLIGHT takes 1..%d", rt_context::kMaxInflight);
+      ctx->batch_inflight = value;
       return RT_OK;
     default:
       return fail(ctx, RT_ERR_INVALID_ARGUMENT, "unknown option %d", option);
@@ -975,9 +989,12 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   ResolveParams rp{};
   // Single frames keep two launches in flight (see rt_context::inflight) unless a per-frame diagnostic output
   // (segments, hits) is on: those buffers describe ONE frame and two kernels must not write them at once.
-  const bool pipelined = batch == 1u && ctx->inflight >= 2 && !(ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS));
-  const int lane = static_cast<int>(ctx->pipe_frames % static_cast<uint64_t>(ctx->inflight < 1 ? 1 : ctx->inflight));
-  hipStream_t render_stream = pipelined ? ctx->render_stream[lane] : ctx->stream;
+  // Multi-frame launches overlap the same way when RT_OPT_BATCH_INFLIGHT >= 2 (each lane then stages a whole batch).
+  const int lanes = batch == 1u ? ctx->inflight : ctx->batch_inflight;
+  const bool pipelined = lanes >= 2 && !(ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS));
+  const int lane = static_cast<int>(ctx->pipe_frames % static_cast<uint64_t>(lanes < 1 ? 1 : lanes));
+  const int stream_index = lane;
+  hipStream_t render_stream = pipelined ? ctx->render_stream[stream_index] : ctx->stream;
   float *staging = nullptr;
   if (batch > 1u || pipelined) {
     const size_t frame_stride = static_cast<size_t>(fp.frame_tile_rows) * 8u * ctx->width;
@@ -1080,15 +1097,42 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   if (pipelined) {
     // this lane's sample buffer is free once the resolve that read it (two frames ago) has run
     if (ctx->resolve_pending[lane]) RT_HIP(ctx, hipStreamWaitEvent(render_stream, ctx->ev_resolved[ctx->resolve_slot[lane]], 0));
-    if (ctx->prep_pending && ctx->prep_seen[lane] != ctx->prep_generation) {
+    if (ctx->prep_pending && ctx->prep_seen[stream_index] != ctx->prep_generation) {
       RT_HIP(ctx, hipStreamWaitEvent(render_stream, ctx->prep_done, 0));
-      ctx->prep_seen[lane] = ctx->prep_generation;
+      ctx->prep_seen[stream_index] = ctx->prep_generation;
     }
   }
-  RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], render_stream));
   LaunchConfig lc{};
   lc.variant = ctx->variant;
   lc.refill_min = ctx->refill_min < 1 ? 1 : (ctx->refill_min > 64 ? 64 : ctx->refill_min);
+  lc.tile_chunk = ctx->tile_chunk;
+  lc.flags = ctx->flags;
+  fp.queue = nullptr;
+  fp.queue_shard_cap = 0;
+  fp.queue_plane = 0;
+  if (pick_variant(ctx->scene, fp, lc) == 4) {  // streamed: the launch needs a path queue and the bounce pass its grid
+    const int qi = pipelined ? lane : static_cast<int>(rt_context::kMaxInflight);
+    const uint32_t shard_cap = stream_queue_shard_cap(fp);
+    const size_t plane = static_cast<size_t>(shard_cap) * kQueueShards;
+    if (ctx->queue_cap[qi] < 4 * plane) {
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the main stream has waited for every render so far
+      (void)hipFree(ctx->d_queue[qi]);
+      ctx->d_queue[qi] = nullptr;
+      ctx->queue_cap[qi] = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_queue[qi], 4 * plane * sizeof(float4)));
+      ctx->queue_cap[qi] = 4 * plane;
+    }
+    fp.queue = ctx->d_queue[qi];
+    fp.queue_shard_cap = shard_cap;
+    fp.queue_plane = plane;
+    if (ctx->stream_occupancy_records != ctx->scene.image_records) {
+      ctx->stream_occupancy_blocks = stream_blocks_per_cu(static_cast<size_t>(ctx->scene.image_records) * sizeof(float4));
+      ctx->stream_occupancy_records = ctx->scene.image_records;
+    }
+    const int per_cu_stream = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->stream_occupancy_blocks > 0 ? ctx->stream_occupancy_blocks : 4);
+    lc.stream_blocks = per_cu_stream * ctx->cu_count;
+  }
+  RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], render_stream));
   int per_cu = ctx->blocks_per_cu;
   if (per_cu <= 0 && ctx->variant == 2) {  // only the resident-wave shape sizes its grid by occupancy
     if (ctx->occupancy_records != ctx->scene.image_records) {
@@ -1099,8 +1143,6 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   }
   if (per_cu <= 0) per_cu = 4;
   lc.persistent_blocks = per_cu * ctx->cu_count;
-  lc.tile_chunk = ctx->tile_chunk;
-  lc.flags = ctx->flags;
   int variant_used = -1, stage_used = -1;
   const int lrc = launch_render(ctx->scene, fp, lc, render_stream, &variant_used, &stage_used);
   if (lrc != 0) return fail(ctx, RT_ERR_DEVICE, "render launch failed: %s", hipGetErrorString(static_cast<hipError_t>(lrc)));
@@ -1338,6 +1380,19 @@ int rt_get_resolve_history(rt_context *ctx, uint32_t n, float *resolve_ms) {
     const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - n + k) % rt_context::kRing);
     RT_HIP(ctx, hipEventElapsedTime(&resolve_ms[k], ctx->ev_stop[slot], ctx->ev_resolved[slot]));
   }
+  return RT_OK;
+}
+
+int rt_get_launch_span(rt_context *ctx, uint32_t n, float *span_ms) {
+  if (!ctx || !span_ms || n == 0) return RT_ERR_INVALID_ARGUMENT;
+  if (n > rt_context::kRing / 2 || n > ctx->stats.frames)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_get_launch_span: %u launches asked, %llu made, ring keeps %u", n,
+                static_cast<unsigned long long>(ctx->stats.frames), rt_context::kRing / 2);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t first = static_cast<uint32_t>((ctx->stats.frames - n) % rt_context::kRing);
+  const uint32_t last = static_cast<uint32_t>((ctx->stats.frames - 1) % rt_context::kRing);
+  RT_HIP(ctx, hipEventElapsedTime(span_ms, ctx->ev_start[first], ctx->ev_stop[last]));
   return RT_OK;
 }
 

@@ -346,7 +346,7 @@ def _batch_vs_sequential(device, scene, size, sky, rnd, jitters, first_pc, accum
     return states, device.stats()
 
 
-@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [-1, 0, 1, 2, 3, 4])
 @pytest.mark.parametrize("accum", [N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32])
 def test_batch_launch_equals_sequential_frames(device, variant, accum):
     """rt_render_frames: 5 frames in one launch == 5 rt_render_frame calls, texels and floats bit for bit."""
@@ -357,6 +357,32 @@ def test_batch_launch_equals_sequential_frames(device, variant, accum):
     assert st.last_batch == 5 and st.last_pixels == 5 * 203 * 101
     assert np.array_equal(seq[0], bat[0])
     assert np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32))
+
+
+@pytest.mark.parametrize("refill_min,tile_chunk", [(1, 1), (1, 2), (9, 3), (64, 1)])
+def test_streamed_shape_primary_pass_queue_bounce_pass(device, refill_min, tile_chunk):
+    """Variant 4 (primary pass -> path queue -> resident waves refilled from the queue) in a multi-frame launch: the
+    launch really takes that shape, and texels, floats and the segment / rough-hit totals equal the sequential frames'
+    whatever the refill threshold and the chunk a wave takes off the queue."""
+    scene = cases.headline_scene(24)
+    sky, rnd = cases.inputs(256, 128)
+    jit = [(0.1, -0.2), (-0.33, 0.27), (0.45, 0.05), (-0.49, -0.49), (0.0, 0.31), (0.2, 0.2)]
+    device.set_option(N.RT_OPT_REFILL_MIN, refill_min)
+    device.set_option(N.RT_OPT_TILE_CHUNK, tile_chunk)
+    try:
+        (seq, bat), st = _batch_vs_sequential(device, scene, (333, 187), sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 4)
+        assert st.last_variant == 4 and st.last_batch == 6
+        assert np.array_equal(seq[0], bat[0])
+        assert np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32))
+        batch_segments, batch_rough = st.last_segments, st.last_rough_hits
+        device.set_variant(3)
+        (seq3, bat3), st3 = _batch_vs_sequential(device, scene, (333, 187), sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 3)
+        assert st3.last_variant == 3
+        assert (st3.last_segments, st3.last_rough_hits) == (batch_segments, batch_rough)
+        assert np.array_equal(bat3[1].view(np.uint32), bat[1].view(np.uint32))
+    finally:
+        device.set_option(N.RT_OPT_REFILL_MIN, 1)
+        device.set_option(N.RT_OPT_TILE_CHUNK, 2)
 
 
 def test_batch_launch_restarting_accumulation_and_oracle(device):
