@@ -1,0 +1,23 @@
+#!/bin/bash
+# Everything profiles/ holds for a round, collected on ONE GPU box in one go:
+#   bash tools/collect_round.sh gpurun_out/prof_rNN
+set -e
+OUT=$(realpath -m "$1"); REPO=$(pwd); mkdir -p "$OUT"
+bash tools/profile_round.sh "$OUT" > "$OUT/profile_round.log" 2>&1
+echo "profile_round done"
+python3 tools/trace_union.py "$OUT/stats" > "$OUT/trace_union.txt"
+python3 tools/trace_union.py "$OUT/stats_one_at_a_time" >> "$OUT/trace_union.txt"
+cat "$OUT/trace_union.txt"
+python bench.py --steps 20 --warmup 5 > "$OUT/bench_driver_flags.json" 2> /dev/null
+python bench.py --batch-inflight 1 --no-cpu-baseline > "$OUT/bench_one_launch_at_a_time.json" 2> /dev/null
+echo "bench lines done"
+bash tools/other_configs.sh "$OUT/other_configs_bench.jsonl" 2> /dev/null
+echo "other configs done"
+python tools/config5.py 2>&1 | grep -v amdgpu.ids > "$OUT/config5_one_gpu.txt" || true
+python tools/batch_times.py 2>&1 | grep -v amdgpu.ids > "$OUT/batch_and_partition_times.txt" || true
+python tools/inflight_times.py 2>&1 | grep -v amdgpu.ids > "$OUT/inflight_times.txt" || true
+echo "times done"
+RT355_LIB=$REPO/rsraytracingv3_amd/librt355_prof.so python tools/phase_profile.py --batch 8 2>&1 | grep -v amdgpu.ids > "$OUT/phases.txt"
+RT355_LIB=$REPO/rsraytracingv3_amd/librt355_prof.so python tools/phase_profile.py --batch 1 2>&1 | grep -v amdgpu.ids >> "$OUT/phases.txt"
+RT355_LIB=$REPO/rsraytracingv3_amd/librt355_prof.so python tools/phase_profile.py --batch 8 --variant 4 2>&1 | grep -v amdgpu.ids >> "$OUT/phases.txt"
+cat "$OUT/phases.txt"

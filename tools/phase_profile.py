@@ -35,6 +35,8 @@ scene = cases.headline_scene(8) if args.spheres == 64 else cases.stress_scene(ar
 dev = Device(0)
 dev.set_outputs(N.RT_OUT_RGBA8)
 dev.set_variant(args.variant)
+dev.set_option(N.RT_OPT_BATCH_INFLIGHT, 1)  # one launch at a time: the kernel time printed is one kernel's alone
+dev.set_option(N.RT_OPT_INFLIGHT, 1)
 target = RenderTarget.new(dev, (W, H))
 rt = RandomTexture(dev)
 rt.write(synth.random_texture(1))
