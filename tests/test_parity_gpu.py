@@ -4,6 +4,8 @@ Both sides implement the same written float32 specification independ
 the bar is exact equality of the linear-float output, the stored sRGB8 texels, the per-pixel
 segment counts and the per-segment hit indices.  The 1e-4 tolerance BASELINE.json states is
 asserted as well (it is implied)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -520,3 +522,62 @@ def test_intermediate_frames_of_a_batch_launch(device, accum):
                     assert rc == -1  # RT_ERR_INVALID_ARGUMENT: that frame was not kept
     finally:
         device.call("rt_keep_batch_frames", 0)
+
+
+@pytest.mark.parametrize("accum", [N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32])
+def test_multi_frame_launches_in_flight_equal_one_at_a_time(device, accum):
+    """RT_OPT_BATCH_INFLIGHT (default 2; here 3, 2 and 1) with RT_OPT_INFLIGHT 4 / 2 / 1: a mixed sequence of multi-frame
+    launches and single frames, queued without a sync, the random texture replaced on the device in between — launches
+    overlap on the internal streams, the history is folded strictly in frame order, so texels and floats equal those of
+    one launch at a time.  rt_get_launch_span: the device time of overlapping launches is less than the sum of their
+    kernel times and at least the longest of them."""
+    scene = cases.headline_scene(7)
+    size = (264, 136)
+    sky, _ = cases.inputs(256, 128)
+    sequence = [5, 1, 3, 1, 1, 2, 8, 1, 4]  # frames per launch
+    total = sum(sequence)
+    jit = synth.jitter_sequence(11, total)
+    results = {}
+    try:
+        for lanes_batch, lanes_single in ((3, 4), (2, 2), (1, 1)):
+            device.set_partition(0, 1, 8)
+            device.set_accum_mode(accum)
+            device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
+            device.set_variant(-1)
+            device.set_option(N.RT_OPT_BATCH_INFLIGHT, lanes_batch)
+            device.set_option(N.RT_OPT_INFLIGHT, lanes_single)
+            target = RenderTarget.new(device, size)
+            rt = RandomTexture(device, seed=90)
+            rt.generate_on_device()
+            conn = Connection(scene, device, sky, rt, max_objects="live")
+            conn.update_buffers(size, scene, (0.0, 0.0))
+            rt.seed = 90
+            k = 0
+            for n, frames in enumerate(sequence):
+                if n % 3 == 0:
+                    rt.generate_on_device()
+                if frames == 1:
+                    conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
+                    conn.frame_data.progressive_count = k
+                    conn.draw()
+                else:
+                    conn.draw_frames([(float(x), float(y)) for x, y in jit[k:k + frames]], k)
+                k += frames
+            device.sync()
+            n_launches = len(sequence)
+            kms = np.zeros(n_launches, np.float32)
+            device.call("rt_get_frame_history", n_launches, None, None, kms.ctypes.data_as(C.c_void_p))
+            span = C.c_float(0.0)
+            device.call("rt_get_launch_span", n_launches, C.byref(span))
+            assert span.value >= float(kms.max()) * 0.999
+            if lanes_batch == 1 and lanes_single == 1:
+                assert span.value >= float(kms.sum()) * 0.999  # one at a time: the kernels do not overlap
+            results[lanes_batch] = (target.read_rgbf32(), target.read_rgba8())
+    finally:
+        device.set_option(N.RT_OPT_BATCH_INFLIGHT, 2)
+        device.set_option(N.RT_OPT_INFLIGHT, 4)
+    for lanes in (3, 2):
+        assert np.array_equal(results[lanes][0].view(np.uint32), results[1][0].view(np.uint32))
+        assert np.array_equal(results[lanes][1], results[1][1])
+    with pytest.raises(N.RtError):
+        device.set_option(N.RT_OPT_BATCH_INFLIGHT, 9)
