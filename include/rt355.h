@@ -71,11 +71,11 @@ typedef struct rt_stats {
   uint64_t last_cull_mismatches; /* RT_OPT_CULL = 2: primary rays whose culled scan disagreed with the
                                     full scan in the last frame (must be 0)                    */
   float last_resolve_ms;      /* HIP-event time of the last launch's history-resolve pass (n_frames > 1) */
-  uint32_t last_variant;      /* launch shape the last launch used (RT_OPT_VARIANT values 0..3)       */
+  uint32_t last_variant;      /* launch shape the last launch used (RT_OPT_VARIANT values 0..4)       */
   uint32_t last_stage;        /* render_tiles (variant 0/1): what that launch staged into LDS: 0 nothing, 1 sphere
                                  records, 2 the whole scene image, 3 sphere records + the sphere grid (secondary rays
                                  walk the grid); render_blocks (variant 3): 10 * waves per workgroup + waves per SIMD
-                                 its registers are budgeted for (26 multi-frame launches, 25 single frames)   */
+                                 its registers are budgeted for (26 multi-frame launches, 25 single frames); 40 for variant 4   */
   uint32_t grid_cells, grid_items; /* the current scene's sphere grid (0 = none: small scene, or not buildable) */
 } rt_stats;
 
@@ -248,10 +248,13 @@ RT355_API const char *rt_last_error(rt_context *ctx);
 enum {
   RT_OPT_VARIANT = 0,      /* -1 (default) choose per launch; 0 one 8x8 tile per wave, sphere records in
                               LDS; 1 same, records from global memory; 2 resident waves that refill
-                              finished lanes; 3 tiles whose workgroup re-packs surviving paths      */
-  RT_OPT_REFILL_MIN = 1,   /* variant 2: idle lanes a wave tolerates before pulling pixels (1..64) */
-  RT_OPT_BLOCKS_PER_CU = 2,/* variant 2: resident workgroups per CU (0 = occupancy query)       */
-  RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump */
+                              finished lanes; 3 tiles whose workgroup re-packs surviving paths; 4 streamed
+                              (sample-only launches: primary pass -> path queue in global memory -> resident
+                              waves refilled from the queue after every bounce; else falls back to 3)        */
+  RT_OPT_REFILL_MIN = 1,   /* variants 2 and 4: idle lanes a wave tolerates before pulling work (1..64) */
+  RT_OPT_BLOCKS_PER_CU = 2,/* variants 2 and 4: resident workgroups per CU (0 = occupancy query) */
+  RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump; variant 4: 64-path
+                              units a wave takes off the path queue at a time */
   RT_OPT_FLAGS = 4,        /* experiment switches (speed only)                                     */
   RT_OPT_CULL = 5,         /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
                               scan is re-done in full and disagreements are counted in rt_stats     */

@@ -87,6 +87,22 @@ struct FrameParams {
   uint32_t hdri_w, hdri_h;
   const float *rnd;
   uint32_t rnd_w, rnd_h;
+  // float(size) and float(size - 1) of the two textures and float(width), float(height): the conversions the texel
+  // addressing and the pixel coordinate need, done once on the host (set_size_floats) so that the kernels read them as
+  // scalar operands
+  float hdri_wf, hdri_hf, hdri_w1f, hdri_h1f, rnd_wf, rnd_hf, rnd_w1f, rnd_h1f, width_f, height_f;
+  __host__ void set_size_floats() {
+    hdri_wf = static_cast<float>(hdri_w);
+    hdri_hf = static_cast<float>(hdri_h);
+    hdri_w1f = static_cast<float>(hdri_w - 1u);
+    hdri_h1f = static_cast<float>(hdri_h - 1u);
+    rnd_wf = static_cast<float>(rnd_w);
+    rnd_hf = static_cast<float>(rnd_h);
+    rnd_w1f = static_cast<float>(rnd_w - 1u);
+    rnd_h1f = static_cast<float>(rnd_h - 1u);
+    width_f = static_cast<float>(width);
+    height_f = static_cast<float>(height);
+  }
   // row-strip partition (rt_set_partition)
   uint32_t rank, world, strip_rows, local_rows;
   // outputs

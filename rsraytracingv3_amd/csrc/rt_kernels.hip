@@ -6,13 +6,15 @@
 // follows ray.hlsl:97-107 exactly (App. B D10: strict '<' in ascending object order ==
 // lexicographic min of (distance, index)).
 //
-// Three launch shapes share the per-segment code (rt_set_option(RT_OPT_VARIANT); -1 = pick by size):
+// Four launch shapes share the per-segment code (rt_set_option(RT_OPT_VARIANT); -1 = pick by size):
 //   render_tiles       (0 / 1) one 8x8 pixel tile per wave, lanes idle once their path has ended;
 //                      sphere records from LDS (0) or straight from global memory (1)
 //   render_persistent  (2) resident waves pull 8x8 tiles from sharded device counters and REFILL
 //                      lanes whose path ended with the next pixels (ballot + mbcnt rank)
 //   render_blocks      (3) one tile per wave, but after every bounce the workgroup packs its
 //                      surviving paths into as few waves as possible through LDS and ends the rest
+//   primary_stream +   (4) one tile per wave for the primary segment only; surviving paths go through a queue in
+//   bounce_stream      global memory to resident waves that refill finished lanes from it (sample-only launches)
 //
 // The square root of the sphere test is only evaluated when some lane of the wave can still
 // accept the sphere (ballot over "discriminant >= 0 and the sphere is in front"): lanes the
@@ -135,7 +137,7 @@ struct Rng {
 __device__ __forceinline__ size_t rng_texel(const FrameParams &fp, const Rng &rng) {
   const float sx = rng.px + rng.seed, sy = rng.py + rng.seed;
   const float cx = sx - floorf(sx), cy = sy - floorf(sy);
-  const uint32_t i = texel_index(cx, fp.rnd_w), j = texel_index(cy, fp.rnd_h);
+  const uint32_t i = texel_index(cx, fp.rnd_wf, fp.rnd_w1f), j = texel_index(cy, fp.rnd_hf, fp.rnd_h1f);
   return static_cast<size_t>(j) * fp.rnd_w + i;
 }
 // rng_next_seed: rng_seed = (rng_seed + x * 532.3412) % 600.  The seed stays in [0, 1200) for texture
@@ -171,7 +173,7 @@ __device__ __forceinline__ f3 hemisphere(Rng &rng, f3 n, float inv_exp, float x1
 __device__ __forceinline__ f3 sample_hdri(const FrameParams &fp, f3 d) {
   const float u = fmaf(atan2_spec(d.x, d.z), kInvTwoPi, 0.5f);
   const float v = fmaf(asin_spec(-d.y), kInvPi, 0.5f);
-  const uint32_t i = texel_index(u, fp.hdri_w), j = texel_index(v, fp.hdri_h);
+  const uint32_t i = texel_index(u, fp.hdri_wf, fp.hdri_w1f), j = texel_index(v, fp.hdri_hf, fp.hdri_h1f);
   const float4 t = fp.hdri[static_cast<size_t>(j) * fp.hdri_w + i];
   return mk3(t.x, t.y, t.z);
 }
@@ -492,7 +494,7 @@ __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, ui
   // D14: SV_POSITION.xy = pixel centre
   const float pjx = (static_cast<float>(x) + 0.5f) + fp.jitter[2u * frame];
   const float pjy = (static_cast<float>(y) + 0.5f) + fp.jitter[2u * frame + 1u];
-  const float cjx = pjx / static_cast<float>(fp.width), cjy = pjy / static_cast<float>(fp.height);
+  const float cjx = pjx / fp.width_f, cjy = pjy / fp.height_f;
   s.rng = Rng{42.0f, cjx, cjy};
   f3 pw = fma3(fp.cam_right, cjx * fp.vp_width, fp.top_left);
   pw = fma3(fp.cam_neg_up, cjy * fp.vp_height, pw);
@@ -929,8 +931,11 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
 //   bounce_stream   resident waves take chunks of paths off the queue and REFILL lanes whose path has ended from
 //                   it after every bounce, so scans run with full waves until the queue is dry — no per-bounce
 //                   barrier, no workgroup re-packing; waves synchronise once (scene image staged into LDS).
-// Pixel results do not depend on which lane carries a path, so the frame stays bit-identical.  Worth it when a
-// launch holds many paths per resident wave (multi-frame launches); a single 1080p frame has ~200.
+// Pixel results do not depend on which lane carries a path, so the frame stays bit-identical.  Needs many paths per
+// resident wave (multi-frame launches; a single 1080p frame has ~200).  Its refill waits on four 16-byte loads per
+// bounce (16 % of a wave's time) — but prefetching the records into an LDS ring with global_load_lds_dwordx4
+// (tools/microbench/lds_dma.hip) made it 1 % SLOWER: the SIMDs are issue-bound, another wave always has work, and
+// the ring's bookkeeping is more instructions.
 #ifndef RT_STREAM_NW1
 #define RT_STREAM_NW1 4  // waves (tiles) per workgroup of the primary pass
 #endif

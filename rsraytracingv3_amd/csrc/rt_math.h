@@ -202,4 +202,13 @@ RT_HD uint32_t texel_index(float u, uint32_t size) {
   return static_cast<uint32_t>(t);
 }
 
+// The same with the two conversions done by the caller (size_f = float(size), last_f = float(size - 1)): on the device
+// they are wave-uniform kernel arguments, read as scalar operands instead of being converted — and kept — in vector
+// registers.
+RT_HD uint32_t texel_index(float u, float size_f, float last_f) {
+  float t = floorf(u * size_f);
+  t = fminf(fmaxf(t, 0.0f), last_f);
+  return static_cast<uint32_t>(t);
+}
+
 }  // namespace rt355

@@ -960,6 +960,7 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   fp.hdri = ctx->d_hdri;
   fp.hdri_w = ctx->hdri_w;
   fp.hdri_h = ctx->hdri_h;
+  fp.set_size_floats();
   fp.rank = ctx->rank;
   fp.world = ctx->world;
   fp.strip_rows = ctx->strip_rows;
