@@ -21,6 +21,19 @@
 // reference rejects never use the root, so skipping it is exact.
 #include <hip/hip_runtime.h>
 
+#ifndef RT_SHADE_SQRT_RN
+#define RT_SHADE_SQRT_RN 1  // 1 = the shading code's square roots through sqrt_rn (below: 11 instructions, correctly rounded for
+                            // every float, rt_selftest_sqrt) instead of hipcc's 16-instruction sqrtf expansion.  A/B on one
+                            // device: +0.6 % (it cost 5 % while the kernel had no register to spare)
+#endif
+#if RT_SHADE_SQRT_RN && defined(__HIP_DEVICE_COMPILE__)
+namespace rt355 {
+namespace {
+__device__ __forceinline__ float sqrt_rn(float x);
+}
+}  // namespace rt355
+#define RT_SQRTF(x) sqrt_rn(x)
+#endif
 #include "rt_device.h"
 
 static_assert(rt355::kSphBatch == 8, "the scan loop consumes 8 sphere records per trip");
@@ -113,8 +126,14 @@ __device__ __forceinline__ float sqrt_rn(float x) {
 #define RT_PH_ARGS
 #endif
 
-// The same for divergent code (lanes test different spheres): the rare small-input branch is per lane.
-__device__ __forceinline__ float sqrt_rn_lane(float x) {
+// The root of the sphere test, t = -dn - sqrt(q): sqrt_rn without its small-input branch.  For q >= 2^-96 (and +0)
+// this IS the correctly rounded root.  For 0 < q < 2^-96 the residuals may underflow and the result is only some value
+// r in [0, 2^-47] (one of v_sqrt_f32's result and its two neighbours) — which gives the same hit key as the exact root,
+// itself below 2^-48: when -dn >= 2^-22 both are less than a quarter ulp of -dn and fl(-dn - r) = -dn either way; when
+// -dn < 2^-22 then t <= -dn < EPSILON (1e-6) for every r >= 0 and the sphere is rejected either way (ray.hlsl:53-68
+// accepts t >= EPSILON only).  Two instructions fewer per tested sphere than sqrt_rn; tools/fuzz_parity.py and the
+// degenerate-sphere cases of tests/test_parity_gpu.py cover it.
+__device__ __forceinline__ float sqrt_for_hit(float x) {
   const float s = __builtin_amdgcn_sqrtf(x);
   const float sd = __uint_as_float(__float_as_uint(s) - 1u);
   const float su = __uint_as_float(__float_as_uint(s) + 1u);
@@ -122,7 +141,6 @@ __device__ __forceinline__ float sqrt_rn_lane(float x) {
   const float ru = fmaf(-su, s, x);
   float r = (rd <= 0.0f) ? sd : s;
   r = (ru > 0.0f) ? su : r;
-  if ((__float_as_uint(x) - 1u) < (0x0f800000u - 1u)) r = sqrtf(x);
   return r;
 }
 constexpr uint32_t kGridMaxDimDevice = 64;  // = kGridMaxDim of rt_grid.h
@@ -158,7 +176,7 @@ __device__ __forceinline__ float rng_next_seed(float seed, float x) {
 __device__ __forceinline__ f3 hemisphere(Rng &rng, f3 n, float inv_exp, float x1, float x2, float seed1) {
   rng.seed = rng_next_seed(seed1, x2);
   const float cos_theta = pow_spec(x1, inv_exp);
-  const float sin_theta = sqrtf(fmaf(-cos_theta, cos_theta, 1.0f));
+  const float sin_theta = RT_SQRTF(fmaf(-cos_theta, cos_theta, 1.0f));
   const float phi = kTwoPi * x2;
   float sphi, cphi;
   sincos_spec(phi, sphi, cphi);
@@ -240,7 +258,7 @@ __device__ __forceinline__ SphereHit scan_spheres(const float4 *__restrict__ sph
   const unsigned long long cand = __builtin_amdgcn_fcmpf(fminf(q, -dn), 0.0f, 3 /* OGE */);
 #define RT_SPHERE_POST(idx, dn, q, cand)                                     \
   if (cand != 0ull) {                                                        \
-    const uint32_t key = __float_as_uint(-dn - sqrt_rn(q)) - kEpsBits;       \
+    const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;       \
     slot = (key < best_key) ? static_cast<int>(idx) : slot;                  \
     best_key = min(best_key, key);                                           \
   }
@@ -318,7 +336,7 @@ __device__ __forceinline__ SphereHit scan_spheres_coop(const float4 *__restrict_
     const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
     const unsigned long long cand = __builtin_amdgcn_fcmpf(has_ray ? fminf(q, -dn) : -1.0f, 0.0f, 3 /* OGE */);
     if (cand != 0ull) {
-      const uint32_t k = __float_as_uint(-dn - sqrt_rn(q)) - kEpsBits;
+      const uint32_t k = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;
       const bool take = has_ray & (k < key);
       slot = take ? static_cast<int>(j) : slot;
       key = take ? k : key;
@@ -363,7 +381,7 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
       const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
       const unsigned long long cand = __builtin_amdgcn_fcmpf(fminf(q, -dn), 0.0f, 3 /* OGE */);
       if (cand != 0ull) {
-        const uint32_t key = __float_as_uint(-dn - sqrt_rn(q)) - kEpsBits;
+        const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;
         slot = (key < best_key) ? static_cast<int>(i) : slot;
         best_key = min(best_key, key);
       }
@@ -420,7 +438,7 @@ __device__ __forceinline__ SphereHit scan_grid(const SceneView &sv, const GridPa
       const float dn = fmaf(d.z, nzv, fmaf(d.y, nyv, d.x * nxv));
       const float q = fmaf(dn, dn, -(fmaf(nzv, nzv, fmaf(nyv, nyv, nxv * nxv)) - g.w));
       if (fminf(q, -dn) >= 0.0f) {
-        const uint32_t key = __float_as_uint(-dn - sqrt_rn_lane(q)) - kEpsBits;
+        const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;
         const bool take = (key < best_key) | ((key == best_key) & (slot < best_slot));
         best_slot = take ? slot : best_slot;
         best_key = take ? key : best_key;
@@ -1378,7 +1396,15 @@ __global__ void math_unary_kernel(int op, const float *x, float *y, size_t n) {
 __global__ void math_binary_kernel(int op, const float *a, const float *b, float *y, size_t n) {
   const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  y[i] = op == 0 ? atan2_spec(a[i], b[i]) : (op == 1 ? pow_spec(a[i], b[i]) : a[i] / b[i]);
+  // ops 3 / 4: the sphere test's hit key bits(-dn - root(q)) - bits(EPSILON) for a = dn, b = q, with the scan's branch-free
+  // root and with the IEEE root — equal for every (dn, q) the scan can ask about (tests/test_parity_gpu.py)
+  if (op == 3) {
+    y[i] = __uint_as_float(__float_as_uint(-a[i] - sqrt_for_hit(b[i])) - kEpsBits);
+  } else if (op == 4) {
+    y[i] = __uint_as_float(__float_as_uint(-a[i] - sqrtf(b[i])) - kEpsBits);
+  } else {
+    y[i] = op == 0 ? atan2_spec(a[i], b[i]) : (op == 1 ? pow_spec(a[i], b[i]) : a[i] / b[i]);
+  }
 }
 
 // Every non-negative float through the kernel's sqrt_rn against hipcc's correctly rounded sqrtf.

@@ -54,9 +54,14 @@ RT_HD float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x));
 RT_HD f3 cross3(f3 a, f3 b) {
   return f3{fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
 }
-RT_HD float length3(f3 a) { return sqrtf(dot3(a, a)); }
+// The correctly rounded square root of the shading code.  A device translation unit may define RT_SQRTF as its own
+// correctly rounded form before including this header (rt_kernels.hip: sqrt_rn, 11 instructions instead of hipcc's 16).
+#ifndef RT_SQRTF
+#define RT_SQRTF(x) sqrtf(x)
+#endif
+RT_HD float length3(f3 a) { return RT_SQRTF(dot3(a, a)); }
 RT_HD f3 normalize3(f3 a) {
-  const float inv = 1.0f / sqrtf(dot3(a, a));
+  const float inv = 1.0f / RT_SQRTF(dot3(a, a));
   return a * inv;
 }
 RT_HD float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
@@ -130,7 +135,7 @@ RT_HD float asin_spec(float x) {
   const float ax = fminf(fabsf(x), 1.0f);
   const bool big = ax > 0.5f;
   const float z = big ? fmaf(-0.5f, ax, 0.5f) : ax * ax;
-  const float t = big ? sqrtf(z) : ax;
+  const float t = big ? RT_SQRTF(z) : ax;
   float p = fmaf(z, 0x1.59dabcp-5f, 0x1.8ba266p-6f);
   p = fmaf(z, p, 0x1.748c64p-5f);
   p = fmaf(z, p, 0x1.33014ep-4f);

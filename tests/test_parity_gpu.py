@@ -581,3 +581,42 @@ def test_multi_frame_launches_in_flight_equal_one_at_a_time(device, accum):
         assert np.array_equal(results[lanes][1], results[1][1])
     with pytest.raises(N.RtError):
         device.set_option(N.RT_OPT_BATCH_INFLIGHT, 9)
+
+
+def test_branch_free_root_gives_the_exact_hit_key(device):
+    """The scans compute t = -dn - sqrt(q) with a root that is only correctly rounded for q >= 2^-96 (sqrt_for_hit,
+    rt_kernels.hip); below that its value is some r in [0, 2^-47], which must give the same hit key as the IEEE root —
+    bit for bit when the key can be accepted (below the initial distance's key), "never accepted" on both sides
+    otherwise.  Swept over dn of both signs and every magnitude against q from denormals to 1e12, with the binade
+    edges of the argument (2^-96 for q, 2^-22 for -dn, EPSILON for t) put in by hand."""
+    rs = np.random.RandomState(11)
+    n = 1 << 20
+
+    def keys(op, dn, q):
+        y = np.empty_like(dn)
+        device.call("rt_selftest_math_binary", op, dn.ctypes.data_as(C.c_void_p), q.ctypes.data_as(C.c_void_p),
+                    y.ctypes.data_as(C.c_void_p), dn.size)
+        return y.view(np.uint32)
+
+    no_hit = np.uint32(0x49742400 - 0x358637bd)  # key of the initial hit.distance 1e6 (ray.hlsl:98)
+    mag = np.exp(rs.uniform(np.log(1e-45), np.log(1e7), n)).astype(np.float32)
+    dn = (-mag * np.where(rs.uniform(size=n) < 0.85, 1.0, -1.0)).astype(np.float32)
+    q = np.exp(rs.uniform(np.log(1e-46), np.log(1e12), n)).astype(np.float32)
+    tiny = rs.uniform(size=n) < 0.5
+    q[tiny] = np.exp(rs.uniform(np.log(1e-46), np.log(2.0 ** -94), int(tiny.sum()))).astype(np.float32)
+    edge_q = np.array([0.0, 1e-45, 2.0 ** -126, 2.0 ** -97, np.nextafter(np.float32(2.0 ** -96), np.float32(0)), 2.0 ** -96,
+                       np.nextafter(np.float32(2.0 ** -96), np.float32(1)), 1e-30, 1.0], np.float32)
+    edge_dn = -np.array([0.0, 1e-45, 1e-7, np.nextafter(np.float32(2.0 ** -22), np.float32(0)), 2.0 ** -22,
+                         np.nextafter(np.float32(2.0 ** -22), np.float32(1)), 9.99999e-7, 1e-6, 1.0000001e-6, 3e-6, 1.0, 4.0,
+                         999999.9, 1e6], np.float32)
+    gq, gd = np.meshgrid(edge_q, edge_dn)
+    k = gq.size
+    q[:k], dn[:k] = gq.ravel(), gd.ravel()
+    fast, exact = keys(3, dn, q), keys(4, dn, q)
+    with np.errstate(invalid="ignore"):
+        ref = ((-dn - np.sqrt(q)).astype(np.float32).view(np.uint32) - np.uint32(0x358637bd))
+    assert np.array_equal(exact, ref), "device IEEE root key differs from numpy"
+    same = (fast == exact) | ((fast >= no_hit) & (exact >= no_hit))
+    assert same.all(), "%d of %d keys differ, e.g. dn=%r q=%r" % ((~same).sum(), n, dn[~same][:3], q[~same][:3])
+    assert (fast[q >= np.float32(2.0 ** -96)] == exact[q >= np.float32(2.0 ** -96)]).all()
+    assert int(((exact < no_hit) & (q < np.float32(2.0 ** -96))).sum()) > 1000, "the sweep must reach acceptable keys with tiny q"
