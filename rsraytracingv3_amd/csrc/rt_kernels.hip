@@ -808,6 +808,11 @@ __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FramePar
 template <int NW, int WAVES, bool LEAN>
 __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_all[];
+  // The single-frame form (WAVES = 5) overlaps with its neighbours' launches and runs best at 5 waves per SIMD (A/B on
+  // one device: 34.3 against 31.8 - 33.3 Grays/s at 6; holding the occupancy with a larger LDS request instead: 30.1).
+  // Its code fits the 80 registers of 6, so the register count is lifted to the next occupancy step by naming v88 as
+  // clobbered — no instruction, the allocation just becomes 96.
+  if (WAVES == 5) asm volatile("; 5 waves per SIMD: register count held above 88" ::: "v88");
   // Live-path counts of the waves, double-buffered by iteration parity: iteration k writes and reads
   // wave_count[k & 1].  A wave reaches its write of iteration k+2 (same buffer) only after the count
   // barrier of iteration k+1, which every live wave joins after it has finished its iteration-k reads
