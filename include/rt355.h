@@ -268,9 +268,11 @@ enum {
   RT_OPT_GRID_MIN = 7,     /* scenes with at least this many spheres (default 129) get a uniform grid at the next
                               rt_set_scene: secondary rays then test the spheres of the cells they cross instead of
                               every sphere (ray.hlsl:97-107 scans linearly; the reference caps scenes at 80)       */
-  RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8: as RT_OPT_INFLIGHT, each
-                              launch staging its samples in a buffer of its own; the history is updated in frame
-                              order on the context's stream.  1 = one launch at a time.                           */
+  RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 1): as RT_OPT_INFLIGHT,
+                              each launch staging its samples in a buffer of its own; the history is updated in frame
+                              order on the context's stream.  2 hides the resolve pass and the gap between launches
+                              behind the next launch (+1 ... +4 % throughput at 1080p) at the price of a second staging
+                              buffer and of kernel times that overlap (rt_get_launch_span).                        */
 };
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */

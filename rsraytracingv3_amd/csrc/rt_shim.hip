@@ -115,7 +115,7 @@ struct rt_context {
   uint32_t occupancy_records = ~0u;  // ... a scene image of this many records
   static constexpr int kMaxInflight = 8;
   int inflight = 4;
-  int batch_inflight = 2;  // RT_OPT_BATCH_INFLIGHT
+  int batch_inflight = 1;  // RT_OPT_BATCH_INFLIGHT
   uint64_t prep_generation = 0;                 // bumped whenever prep_done is re-recorded
   uint64_t prep_seen[kMaxInflight] = {};        // generation each render stream has already waited for
   int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid

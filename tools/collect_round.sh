@@ -6,10 +6,10 @@ OUT=$(realpath -m "$1"); REPO=$(pwd); mkdir -p "$OUT"
 bash tools/profile_round.sh "$OUT" > "$OUT/profile_round.log" 2>&1
 echo "profile_round done"
 python3 tools/trace_union.py "$OUT/stats" > "$OUT/trace_union.txt"
-python3 tools/trace_union.py "$OUT/stats_one_at_a_time" >> "$OUT/trace_union.txt"
+python3 tools/trace_union.py "$OUT/stats_two_in_flight" >> "$OUT/trace_union.txt"
 cat "$OUT/trace_union.txt"
 python bench.py --steps 20 --warmup 5 > "$OUT/bench_driver_flags.json" 2> /dev/null
-python bench.py --batch-inflight 1 --no-cpu-baseline > "$OUT/bench_one_launch_at_a_time.json" 2> /dev/null
+python bench.py --batch-inflight 2 --no-cpu-baseline > "$OUT/bench_two_in_flight.json" 2> /dev/null
 echo "bench lines done"
 bash tools/other_configs.sh "$OUT/other_configs_bench.jsonl" 2> /dev/null
 echo "other configs done"

@@ -11,9 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 # roofline.avg_launch_ms is about; the full default line (with the extra legs) is traced separately
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 "$REPO/bench.py" --no-extra-legs > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 echo "stats pass (headline leg) done"
-# the same with one launch at a time: kernels do not overlap, the trace's average duration IS the device time per launch
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_one_at_a_time" -o bench -- python3 "$REPO/bench.py" --no-extra-legs --no-cpu-baseline --batch-inflight 1 > "$OUT/bench_one_at_a_time_under_rocprof.json" 2> "$OUT/stats_one_at_a_time.log"
-echo "stats pass (headline leg, one launch at a time) done"
+# the same with two launches in flight (RT_OPT_BATCH_INFLIGHT = 2): kernels overlap, the trace's average duration is not the
+# device time per launch any more (tools/trace_union.py)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_two_in_flight" -o bench -- python3 "$REPO/bench.py" --no-extra-legs --no-cpu-baseline --batch-inflight 2 > "$OUT/bench_two_in_flight_under_rocprof.json" 2> "$OUT/stats_two_in_flight.log"
+echo "stats pass (headline leg, two launches in flight) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_all_legs" -o bench -- python3 "$REPO/bench.py" --no-cpu-baseline > "$OUT/bench_all_legs_under_rocprof.json" 2> "$OUT/stats_all_legs.log"
 echo "stats pass (all legs) done"
 i=0
@@ -21,7 +22,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES" "GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU" \
            "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   i=$((i + 1))
-  rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc$i" -o pmc -- python3 "$REPO/bench.py" --no-cpu-baseline --no-extra-legs --batch-inflight 1 --steps 48 --warmup 16 --min-seconds 0.05 --clock-warmup 0.2 > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.log"
+  rocprofv3 --pmc $set --output-format csv -d "$OUT/pmc$i" -o pmc -- python3 "$REPO/bench.py" --no-cpu-baseline --no-extra-legs --steps 48 --warmup 16 --min-seconds 0.05 --clock-warmup 0.2 > "$OUT/pmc$i.json" 2> "$OUT/pmc$i.log"
   echo "pmc pass $i ($set) done"
 done
 cd "$REPO"
