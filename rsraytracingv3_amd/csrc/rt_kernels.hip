@@ -46,17 +46,22 @@ namespace {
 #define RT_PERSISTENT_WAVES 6  // waves per SIMD the persistent kernel's register budget is held to
 #endif
 #ifndef RT_BLOCKS_WAVES_BATCH
-#define RT_BLOCKS_WAVES_BATCH 6   // waves per SIMD the re-packing shape is budgeted for in multi-frame launches (80 VGPRs)
+#define RT_BLOCKS_WAVES_BATCH 7   // waves per SIMD the re-packing shape is budgeted for in multi-frame launches: 72 VGPRs, no
+                                  // scratch since the instruction diet (A/B on one device: 6 waves / 80 VGPRs 37.7, 7 waves
+                                  // 38.1, 8 waves / 64 VGPRs + 28 B of scratch 35.8 Grays/s)
 #endif
 #ifndef RT_BLOCKS_WAVES_SINGLE
-#define RT_BLOCKS_WAVES_SINGLE 5  // ... and in single-frame launches, several of which are in flight (96 VGPRs, no spills)
+#define RT_BLOCKS_WAVES_SINGLE 5  // ... and in single-frame launches, several of which are in flight (register count held at the 5-wave step)
 #endif
 #ifndef RT_X2_PREFETCH
-#define RT_X2_PREFETCH 1  // request the second random() texel during the scan (0: when the hit turns out rough)
+#define RT_X2_PREFETCH 0  // 1 = request the second random() texel during the scan, 0 = when the hit turns out rough (A/B on one
+                          // device: 0 is +0.3 % since the kernel is issue-bound — the address arithmetic of a texel most
+                          // iterations do not need costs more than its latency)
 #endif
 #ifndef RT_DEFER_SKY_BLOCKS
-#define RT_DEFER_SKY_BLOCKS 0  // render_blocks / render_persistent: 1 = skybox lookup in path_end, 0 = at the miss (A/B on one
-                               // device: deferring costs these shapes 4 %, it pays only in render_tiles)
+#define RT_DEFER_SKY_BLOCKS 1  // render_blocks / render_persistent: 1 = skybox lookup (atan2 + asin + texel, ~75 instructions the
+                               // whole wave executes) in path_end, with the other finished lanes, 0 = at the miss after every
+                               // bounce.  A/B on one device: +1.6 % (it cost 4 % while the kernel had no register to spare)
 #endif
 constexpr int kBlock = 256;
 #ifndef RT_TILES_BLOCK
