@@ -75,11 +75,6 @@ constexpr int kTile = 8;  // 8x8 pixels per tile / wave
                        // 32.5 / 33.1 at 5, 1 wave 32.7 / 30.5, 8 waves 27.0 / 27.5 — hence 2 waves, and the register
                        // budget by launch kind
 #endif
-#ifndef RT_XCD_REMAP
-#define RT_XCD_REMAP 0  // 1 = every XCD gets a contiguous run of tiles (neighbouring tiles share output lines).  A/B on one
-                        // device: headline -0.3 %, one frame per launch -10 % (a contiguous eighth of a frame is all sky or all
-                        // spheres: the XCDs finish at different times) — off
-#endif
 #ifndef RT_XCHG_PATHS
 #define RT_XCHG_PATHS ((RT_BLOCK_NW - 1) * 64)  // re-packing needs the paths to fit one wave fewer
 #endif
@@ -512,7 +507,8 @@ struct Path {
 // `frame`: which frame of the launch's batch (stacked frame_tile_rows tile rows apart in the outputs).
 __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, uint32_t lrow, uint32_t frame, Path &s) {
   // local row -> global row of the round-robin strip partition
-  const uint32_t y = ((lrow / fp.strip_rows) * fp.world + fp.rank) * fp.strip_rows + lrow % fp.strip_rows;
+  // (one GPU: the local rows are the frame's rows — spares the per-lane integer division)
+  const uint32_t y = fp.world == 1u ? lrow : ((lrow / fp.strip_rows) * fp.world + fp.rank) * fp.strip_rows + lrow % fp.strip_rows;
   s.p = (frame * fp.frame_tile_rows * kTile + lrow) * fp.width + x;
   // D14: SV_POSITION.xy = pixel centre
   const float pjx = (static_cast<float>(x) + 0.5f) + fp.jitter[2u * frame];
@@ -707,6 +703,9 @@ __device__ __forceinline__ void path_end(const FrameParams &fp, const Path &s) {
     for (uint32_t i = s.seg; i < fp.reflection_limit; ++i) fp.hits[p * fp.reflection_limit + i] = -2;
 }
 
+// Number of the workgroup in launch order (the tile kernels' grids are 3-D: grid_tile_pos below).
+__device__ __forceinline__ uint32_t linear_block() { return (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
+
 // Frame totals.  A workgroup reduces its four waves through LDS and issues ONE set of atomics,
 // on the totals shard of its own 128-byte line (blockIdx % kTotalShards): device-scope atomics on a
 // single line saturate near 90/us, and one set per wave on one line used to cost more than the
@@ -727,7 +726,7 @@ __device__ __forceinline__ void add_totals(const FrameParams &fp, uint32_t seg, 
   }
   __syncthreads();
   if (threadIdx.x < 3 && block_totals[threadIdx.x] != 0u) {
-    unsigned long long *shard = fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride;
+    unsigned long long *shard = fp.counters + static_cast<size_t>(linear_block() % kTotalShards) * kTotalShardStride;
     atomicAdd(&shard[threadIdx.x], static_cast<unsigned long long>(block_totals[threadIdx.x]));
   }
 }
@@ -742,6 +741,18 @@ __device__ __forceinline__ TilePos tile_pos(const FrameParams &fp, uint32_t tile
   t.col = tile - stacked_row * tiles_x;
   t.frame = stacked_row / fp.frame_tile_rows;
   t.row = stacked_row - t.frame * fp.frame_tile_rows;
+  return t;
+}
+
+// The tile kernels are launched on a 3-D grid — x: tile column / waves per workgroup, y: tile row, z: frame of the batch —
+// so that a wave's tile needs no integer division (tile_pos costs ~50 vector instructions per wave: two 32-bit
+// divisions of a value the compiler cannot prove uniform).
+template <int WAVES_PER_BLOCK>
+__device__ __forceinline__ TilePos grid_tile_pos() {
+  TilePos t;
+  t.col = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  t.row = blockIdx.y;
+  t.frame = blockIdx.z;
   return t;
 }
 
@@ -770,9 +781,8 @@ __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FramePar
   }
   RT_PH_DECL
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-  const TilePos tp = tile_pos(fp, wave, tiles_x);
+  const TilePos tp = grid_tile_pos<THREADS / 64>();
   const uint32_t x = tp.col * kTile + (lane & 7u);
   const uint32_t lrow = tp.row * kTile + (lane >> 3);
   uint32_t seg = 0, rough = 0;
@@ -830,16 +840,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-#if RT_XCD_REMAP
-  // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one): give every XCD a contiguous run of
-  // tiles, so that neighbouring tiles — whose rows share 128-byte lines of the outputs — meet in one L2
-  const uint32_t nb = gridDim.x, xq = nb >> 3, xr = nb & 7u, xcd = blockIdx.x & 7u;
-  const uint32_t block = (xcd < xr ? xcd * (xq + 1u) : xr * (xq + 1u) + (xcd - xr) * xq) + (blockIdx.x >> 3);
-#else
-  const uint32_t block = blockIdx.x;
-#endif
-  const uint32_t tile = block * NW + wave;
-  const TilePos tp = tile_pos(fp, tile, tiles_x);
+  const TilePos tp = grid_tile_pos<NW>();
   const uint32_t x = tp.col * kTile + (lane & 7u);
   const uint32_t lrow = tp.row * kTile + (lane >> 3);
   Path s;
@@ -943,12 +944,12 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
     rough_total += __shfl_xor(rough_total, off, 64);
   }
   if (lane == 0) {
-    unsigned long long *shard = fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride;
+    unsigned long long *shard = fp.counters + static_cast<size_t>(linear_block() % kTotalShards) * kTotalShardStride;
     if (seg_total) atomicAdd(&shard[0], static_cast<unsigned long long>(seg_total));
     if (rough_total) atomicAdd(&shard[1], static_cast<unsigned long long>(rough_total));
     atomicAdd(&shard[2], static_cast<unsigned long long>(iters));
   }
-  RT_PH_FLUSH(fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride)
+  RT_PH_FLUSH(fp.counters + static_cast<size_t>(linear_block() % kTotalShards) * kTotalShardStride)
 }
 
 // Streamed shape (variant 4), for launches of several frames that write float samples only.  Two kernels:
@@ -985,10 +986,8 @@ __global__ void __launch_bounds__(NW * 64) primary_stream(DeviceScene sc, FrameP
   for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
   const SceneView sv = make_view(sc, lds_all, lds_all);
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-  const uint32_t tile = blockIdx.x * NW + wave;
-  const TilePos tp = tile_pos(fp, tile, tiles_x);
+  const TilePos tp = grid_tile_pos<NW>();
   const uint32_t x = tp.col * kTile + (lane & 7u);
   const uint32_t lrow = tp.row * kTile + (lane >> 3);
   Path s;
@@ -1018,7 +1017,7 @@ __global__ void __launch_bounds__(NW * 64) primary_stream(DeviceScene sc, FrameP
   }
   const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
   if (live != 0ull) {  // wave-uniform
-    const uint32_t shard = blockIdx.x % kQueueShards;
+    const uint32_t shard = linear_block() % kQueueShards;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(&fp.tile_counters[shard * 32u], static_cast<uint32_t>(__popcll(live)));
     base = __builtin_amdgcn_readfirstlane(base);
@@ -1034,7 +1033,7 @@ __global__ void __launch_bounds__(NW * 64) primary_stream(DeviceScene sc, FrameP
     }
   }
   add_totals(fp, seg_total, s.rough & 0x7fffffffu, 0u);
-  RT_PH_FLUSH(fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride)
+  RT_PH_FLUSH(fp.counters + static_cast<size_t>(linear_block() % kTotalShards) * kTotalShardStride)
 }
 
 template <int NW, int WAVES>
@@ -1444,7 +1443,8 @@ uint64_t launch_tiles(const FrameParams &fp) {
 }  // namespace
 
 uint32_t stream_queue_shard_cap(const FrameParams &fp) {
-  const uint64_t blocks = (launch_tiles(fp) + RT_STREAM_NW1 - 1) / RT_STREAM_NW1;
+  const uint32_t tiles_x = (fp.width + kTile - 1) / kTile, tiles_y = (fp.local_rows + kTile - 1) / kTile;
+  const uint64_t blocks = static_cast<uint64_t>((tiles_x + RT_STREAM_NW1 - 1) / RT_STREAM_NW1) * tiles_y * fp.batch;  // primary_stream's grid
   return static_cast<uint32_t>((blocks + kQueueShards - 1) / kQueueShards) * RT_STREAM_NW1 * 64u;
 }
 
@@ -1501,44 +1501,43 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
                        static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 4) {
     if (stage_used) *stage_used = 40;
-    const uint32_t blocks1 = static_cast<uint32_t>((tiles + RT_STREAM_NW1 - 1) / RT_STREAM_NW1);
-    hipLaunchKernelGGL((primary_stream<RT_STREAM_NW1>), dim3(blocks1), dim3(RT_STREAM_NW1 * 64), lds_image, stream, sc, fp);
+    hipLaunchKernelGGL((primary_stream<RT_STREAM_NW1>), dim3((tiles_x + RT_STREAM_NW1 - 1) / RT_STREAM_NW1, tiles_y, fp.batch),
+                       dim3(RT_STREAM_NW1 * 64), lds_image, stream, sc, fp);
     uint32_t blocks2 = static_cast<uint32_t>(lc.stream_blocks < 1 ? 1 : lc.stream_blocks);
     const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
     hipLaunchKernelGGL((bounce_stream<RT_STREAM_NW2, RT_STREAM_WAVES>), dim3(blocks2), dim3(RT_STREAM_NW2 * 64), lds_image, stream, sc,
                        fp, static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 3) {
-    const uint32_t blocks = static_cast<uint32_t>((tiles + RT_BLOCK_NW - 1) / RT_BLOCK_NW);
+    const dim3 blocks((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW, tiles_y, fp.batch);  // x: tile columns, y: tile rows, z: frames
     const size_t bytes = lds_image + static_cast<size_t>(kXchgPaths) * 4 * sizeof(float4);
     const bool lean = sample_only(fp);
     if (fp.batch > 1u && lean) {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
-      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
     } else if (lean) {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
-      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
     } else {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
-      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, false>), dim3(blocks), dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, false>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
     }
   } else {
-    const uint32_t blocks = static_cast<uint32_t>((tiles + (kTileBlock / 64) - 1) / (kTileBlock / 64));
+    const dim3 blocks((tiles_x + (kTileBlock / 64) - 1) / (kTileBlock / 64), tiles_y, fp.batch);
     if (stage_used) *stage_used = variant == 1 ? 0 : ((sc.grid.enabled && !(lc.flags & 2)) ? 3 : (image_fits ? 2 : 1));
     if (variant == 1) {
-      hipLaunchKernelGGL(render_tiles<0>, dim3(blocks), dim3(kTileBlock), 0, stream, sc, fp);
+      hipLaunchKernelGGL(render_tiles<0>, blocks, dim3(kTileBlock), 0, stream, sc, fp);
     } else if (sc.grid.enabled && !(lc.flags & 2)) {  // RT_OPT_FLAGS bit 1: ignore the grid (A/B)
       const size_t bytes = lds_sph + (static_cast<size_t>(sc.grid.off_items - sc.grid.off_cells) +
                                       (static_cast<size_t>(sc.grid.n_items) * 2 + 15) / 16) * sizeof(float4);
       if (bytes <= 12u * 1024u) {
-        const uint32_t blocks128 = static_cast<uint32_t>((tiles + 1) / 2);
-        hipLaunchKernelGGL((render_tiles<3, 128>), dim3(blocks128), dim3(128), bytes, stream, sc, fp);
+        hipLaunchKernelGGL((render_tiles<3, 128>), dim3((tiles_x + 1) / 2, tiles_y, fp.batch), dim3(128), bytes, stream, sc, fp);
       } else {
-        hipLaunchKernelGGL((render_tiles<3, kTileBlock>), dim3(blocks), dim3(kTileBlock), bytes, stream, sc, fp);
+        hipLaunchKernelGGL((render_tiles<3, kTileBlock>), blocks, dim3(kTileBlock), bytes, stream, sc, fp);
       }
     } else if (image_fits) {
-      hipLaunchKernelGGL(render_tiles<2>, dim3(blocks), dim3(kTileBlock), lds_image, stream, sc, fp);
+      hipLaunchKernelGGL(render_tiles<2>, blocks, dim3(kTileBlock), lds_image, stream, sc, fp);
     } else {
-      hipLaunchKernelGGL(render_tiles<1>, dim3(blocks), dim3(kTileBlock), lds_sph, stream, sc, fp);
+      hipLaunchKernelGGL(render_tiles<1>, blocks, dim3(kTileBlock), lds_sph, stream, sc, fp);
     }
   }
   return static_cast<int>(hipGetLastError());
