@@ -30,9 +30,11 @@
 namespace rt355 {
 namespace {
 __device__ __forceinline__ float sqrt_rn(float x);
+__device__ __forceinline__ float rcp_of_root(float s);
 }
 }  // namespace rt355
 #define RT_SQRTF(x) sqrt_rn(x)
+#define RT_RCP_OF_ROOT(s) rcp_of_root(s)
 #endif
 #include "rt_device.h"
 
@@ -102,6 +104,22 @@ __device__ __forceinline__ float sqrt_rn(float x) {
   return r;
 }
 
+// 1.0f / s, correctly rounded, for the arguments normalize3 has: s is a correctly rounded square root, i.e. +0, +inf, a
+// NaN, or a normal number in [2^-75, 2^64].  v_rcp_f32 followed by ONE Newton step in fused arithmetic equals the IEEE
+// quotient for every normal s with 2^-126 <= |s| <= 2^126 (tools/microbench/rcp_exhaustive.hip sweeps every float: 0
+// mismatches; rt_selftest_sqrt repeats the sweep for this function); zero, infinity, NaN and denormals take hipcc's
+// division behind a wave-uniform branch that real scenes never enter.  4 instructions instead of 11.
+__device__ __forceinline__ float rcp_of_root(float s) {
+  const float r0 = __builtin_amdgcn_rcpf(s);
+  float r = fmaf(fmaf(-s, r0, 1.0f), r0, r0);
+  const bool special = __builtin_amdgcn_classf(s, 0x2f7);  // anything but a +-normal number
+  if (__builtin_amdgcn_ballot_w64(special) != 0ull) {
+    asm volatile("; rare path: reciprocal of 0 / inf / NaN / a denormal" ::: "memory");  // keeps this a real branch
+    r = special ? 1.0f / s : r;
+  }
+  return r;
+}
+
 // Diagnostic build only (make prof: -DRT_PROFILE_PHASES): per-wave s_memtime deltas of the phases of
 // render_blocks, summed into words 4.. of the launch's counter shard.  Compiles to nothing otherwise.
 #ifdef RT_PROFILE_PHASES
@@ -118,7 +136,15 @@ __device__ __forceinline__ float sqrt_rn(float x) {
       if (ph_acc[k_]) atomicAdd(&(shard)[4 + k_], ph_acc[k_]);
 #define RT_PH_PARAMS , unsigned long long &ph_t, unsigned long long (&ph_acc)[8]
 #define RT_PH_ARGS , ph_t, ph_acc
+// event counts of the same build (tools/phase_profile.py): [0] spheres tested by full scans (per wave), [1] of which the
+// wave took the root + closest-hit update, [2] sphere steps of cooperative scans, [3] spheres tested by listed scans
+__device__ unsigned long long g_prof_cnt[4];
+#define RT_CNT(k, n)                                                                       \
+  {                                                                                        \
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&g_prof_cnt[k], static_cast<unsigned long long>(n)); \
+  }
 #else
+#define RT_CNT(k, n)
 #define RT_PH_DECL
 #define RT_PH_MARK(k)
 #define RT_PH_FLUSH(shard)
@@ -258,6 +284,7 @@ __device__ __forceinline__ SphereHit scan_spheres(const float4 *__restrict__ sph
   const unsigned long long cand = __builtin_amdgcn_fcmpf(fminf(q, -dn), 0.0f, 3 /* OGE */);
 #define RT_SPHERE_POST(idx, dn, q, cand)                                     \
   if (cand != 0ull) {                                                        \
+    RT_CNT(1, 1)                                                             \
     const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;       \
     slot = (key < best_key) ? static_cast<int>(idx) : slot;                  \
     best_key = min(best_key, key);                                           \
@@ -277,6 +304,7 @@ __device__ __forceinline__ SphereHit scan_spheres(const float4 *__restrict__ sph
   }
   // Two batches of 4 per trip, each computed while the next one's LDS reads are in flight
   // (n_sph_pad is a multiple of 8 plus 8 readable never-hit records).
+  RT_CNT(0, end - begin)
   float4 g0 = sph[begin], g1 = sph[begin + 1], g2 = sph[begin + 2], g3 = sph[begin + 3];
   for (uint32_t i = begin; i < end; i += 8) {
     const float4 h0 = sph[i + 4], h1 = sph[i + 5], h2 = sph[i + 6], h3 = sph[i + 7];
@@ -328,6 +356,7 @@ __device__ __forceinline__ SphereHit scan_spheres_coop(const float4 *__restrict_
   uint32_t key = kNoHitKey;
   int slot = -1;
   const uint32_t n = n_sph_pad - kSphBatch;  // records that can hit (the tail records never do)
+  RT_CNT(2, n >> shift)
   for (uint32_t base = 0; base < n; base += G) {
     const uint32_t j = base + sub;             // < n_sph_pad: n is a multiple of 8 and 8 more are readable
     const float4 g = sph[j];
@@ -372,6 +401,7 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
     unsigned long long m = col_mask[w] & row_mask[w];
     m = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(m >> 32))) << 32) |
         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(m)));
+    RT_CNT(3, __popcll(m))
     while (m != 0ull) {
       const uint32_t i = w * 64u + static_cast<uint32_t>(__builtin_ctzll(m));
       m &= m - 1ull;
@@ -649,10 +679,14 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
   } else {
     if (alive) {
       // the second texel is requested half-way through the scan: the first has arrived by then
+#if RT_X2_PREFETCH
       const uint32_t n = sv.n_sph_pad - kSphBatch, half = (n >> 1) & ~7u;
       SphereHit sh = scan_spheres(sv.sph, 0u, half, s.o, s.d);
       RT_REQUEST_X2
       sh = scan_spheres(sv.sph, half, n, s.o, s.d, sh);
+#else
+      const SphereHit sh = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
+#endif
       RT_PH_MARK(1)
       alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     }
@@ -1423,6 +1457,16 @@ __global__ void sqrt_exhaustive_kernel(unsigned long long *mismatches) {
   for (uint64_t u = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; u <= 0x7f800000ull; u += stride) {
     const float x = __uint_as_float(static_cast<uint32_t>(u));
     bad += __float_as_uint(sqrt_rn(x)) != __float_as_uint(sqrtf(x));
+    {  // normalize3's reciprocal: the IEEE quotient for every float up to 2^126 in magnitude (both signs) and for inf / NaN
+      const uint32_t mag = static_cast<uint32_t>(u) & 0x7fffffffu;
+      if (mag <= 0x7e800000u || mag >= 0x7f800000u) {
+        for (uint32_t sign = 0; sign < 2u; ++sign) {
+          const float y = __uint_as_float(static_cast<uint32_t>(u) | (sign << 31));
+          const uint32_t got = __float_as_uint(rcp_of_root(y)), want = __float_as_uint(1.0f / y);
+          bad += got != want && !((got & 0x7fffffffu) > 0x7f800000u && (want & 0x7fffffffu) > 0x7f800000u);
+        }
+      }
+    }
   }
   if (bad) atomicAdd(mismatches, static_cast<unsigned long long>(bad));
 }
@@ -1571,6 +1615,20 @@ int stream_blocks_per_cu(size_t lds_bytes) {
       hipSuccess)
     return 0;
   return n;
+}
+
+int prof_counts(unsigned long long out4[4], bool reset) {
+#ifdef RT_PROFILE_PHASES
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_prof_cnt), 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) {
+    const unsigned long long zero[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof_cnt), zero, sizeof zero) != hipSuccess) return 1;
+  }
+  return 0;
+#else
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  return 0;
+#endif
 }
 
 int persistent_blocks_per_cu(size_t lds_bytes) {

@@ -60,8 +60,13 @@ RT_HD f3 cross3(f3 a, f3 b) {
 #define RT_SQRTF(x) sqrtf(x)
 #endif
 RT_HD float length3(f3 a) { return RT_SQRTF(dot3(a, a)); }
+// 1 / s for s a correctly rounded square root (0, +inf, NaN, or 2^-75 .. 2^64): IEEE division; a device translation
+// unit may define RT_RCP_OF_ROOT as its own correctly rounded form (rt_kernels.hip: rcp_of_root, 4 instructions for 11).
+#ifndef RT_RCP_OF_ROOT
+#define RT_RCP_OF_ROOT(s) (1.0f / (s))
+#endif
 RT_HD f3 normalize3(f3 a) {
-  const float inv = 1.0f / RT_SQRTF(dot3(a, a));
+  const float inv = RT_RCP_OF_ROOT(RT_SQRTF(dot3(a, a)));
   return a * inv;
 }
 RT_HD float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }

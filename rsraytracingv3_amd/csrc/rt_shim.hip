@@ -1344,6 +1344,9 @@ int rt_get_counter_words(rt_context *ctx, uint64_t *out16) {
     out16[w] = 0;
     for (uint32_t sh = 0; sh < kTotalShards; ++sh) out16[w] += line[sh * kTotalShardStride + w];
   }
+  unsigned long long events[4];  // profiling build: event counts since the previous call (words 12..15)
+  if (prof_counts(events, true) == 0)
+    for (int k = 0; k < 4; ++k) out16[12 + k] = events[k];
   return RT_OK;
 }
 

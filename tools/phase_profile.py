@@ -44,7 +44,11 @@ conn = Connection(scene, dev, synth.procedural_skybox(2048, 1024), rt, max_objec
 conn.update_buffers((W, H), scene, (0.0, 0.0))
 jit = synth.jitter_sequence(42, 4096)
 k = 0
-for _ in range(40):
+words = (C.c_uint64 * 16)()
+for it in range(40):
+    if it == 39:  # the event counts (words 12..15) run since the previous read: make them the last launch's
+        dev.sync()
+        dev.call("rt_get_counter_words", words)
     if args.batch == 1:
         conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
         conn.frame_data.progressive_count = k
@@ -53,7 +57,6 @@ for _ in range(40):
         conn.draw_frames(jit[k:k + args.batch], k)
     k += args.batch
 dev.sync()
-words = (C.c_uint64 * 16)()
 dev.call("rt_get_counter_words", words)
 st = dev.stats()
 ph = np.array(words[4:12], dtype=np.float64)
@@ -61,3 +64,8 @@ print("variant %d, %d frame(s) per launch, kernel %.3f ms, %d segments, %d wave 
       % (st.last_variant, args.batch, st.last_kernel_ms, st.last_segments, st.last_wave_iterations))
 for name, v in zip(NAMES, ph):
     print("  %-42s %6.2f %%   %.3e wave-cycles" % (name, 100.0 * v / ph.sum(), v))
+ev = [int(w) for w in words[12:16]]
+if any(ev):
+    print("  events of that launch: full scans tested %d spheres per wave-scan total, root + update taken for %d of them "
+          "(%.1f %%); cooperative scans %d sphere steps; listed (primary) scans %d spheres"
+          % (ev[0], ev[1], 100.0 * ev[1] / max(ev[0], 1), ev[2], ev[3]))
