@@ -136,20 +136,25 @@ __device__ __forceinline__ float rcp_of_root(float s) {
       if (ph_acc[k_]) atomicAdd(&(shard)[4 + k_], ph_acc[k_]);
 #define RT_PH_PARAMS , unsigned long long &ph_t, unsigned long long (&ph_acc)[8]
 #define RT_PH_ARGS , ph_t, ph_acc
-// event counts of the same build (tools/phase_profile.py): [0] spheres tested by full scans (per wave), [1] of which the
-// wave took the root + closest-hit update, [2] sphere steps of cooperative scans, [3] spheres tested by listed scans
-__device__ unsigned long long g_prof_cnt[4];
-#define RT_CNT(k, n)                                                                       \
-  {                                                                                        \
-    if ((threadIdx.x & 63u) == 0) atomicAdd(&g_prof_cnt[k], static_cast<unsigned long long>(n)); \
-  }
 #else
-#define RT_CNT(k, n)
 #define RT_PH_DECL
 #define RT_PH_MARK(k)
 #define RT_PH_FLUSH(shard)
 #define RT_PH_PARAMS
 #define RT_PH_ARGS
+#endif
+
+// Diagnostic build only (make events: -DRT_PROFILE_EVENTS; its atomics slow the kernel several times, so it is a build of
+// its own): event counts since the last rt_get_counter_words — [0] spheres tested by full scans (per wave), [1] of which
+// the wave took the root + closest-hit update, [2] sphere steps of cooperative scans, [3] spheres tested by listed scans.
+#ifdef RT_PROFILE_EVENTS
+__device__ unsigned long long g_prof_cnt[4];
+#define RT_CNT(k, n)                                                                             \
+  {                                                                                              \
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&g_prof_cnt[k], static_cast<unsigned long long>(n)); \
+  }
+#else
+#define RT_CNT(k, n)
 #endif
 
 // The root of the sphere test, t = -dn - sqrt(q): sqrt_rn without its small-input branch.  For q >= 2^-96 (and +0)
@@ -1618,7 +1623,7 @@ int stream_blocks_per_cu(size_t lds_bytes) {
 }
 
 int prof_counts(unsigned long long out4[4], bool reset) {
-#ifdef RT_PROFILE_PHASES
+#ifdef RT_PROFILE_EVENTS
   if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_prof_cnt), 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) {
     const unsigned long long zero[4] = {0, 0, 0, 0};

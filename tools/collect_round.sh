@@ -20,4 +20,5 @@ echo "times done"
 RT355_LIB=$REPO/rsraytracingv3_amd/librt355_prof.so python tools/phase_profile.py --batch 8 2>&1 | grep -v amdgpu.ids > "$OUT/phases.txt"
 RT355_LIB=$REPO/rsraytracingv3_amd/librt355_prof.so python tools/phase_profile.py --batch 1 2>&1 | grep -v amdgpu.ids >> "$OUT/phases.txt"
 RT355_LIB=$REPO/rsraytracingv3_amd/librt355_prof.so python tools/phase_profile.py --batch 8 --variant 4 2>&1 | grep -v amdgpu.ids >> "$OUT/phases.txt"
+RT355_LIB=$REPO/rsraytracingv3_amd/librt355_events.so python tools/phase_profile.py --batch 8 2>&1 | grep "events of that launch" >> "$OUT/phases.txt"
 cat "$OUT/phases.txt"
