@@ -207,7 +207,8 @@ __device__ __forceinline__ float rng_next_seed(float seed, float x) {
 __device__ __forceinline__ f3 hemisphere(Rng &rng, f3 n, float inv_exp, float x1, float x2, float seed1) {
   rng.seed = rng_next_seed(seed1, x2);
   const float cos_theta = pow_spec(x1, inv_exp);
-  const float sin_theta = RT_SQRTF(fmaf(-cos_theta, cos_theta, 1.0f));
+  // 1 - cos^2 is +0 or at least 2^-24 (cos_theta is a float <= 1): the branch-free root is the correctly rounded one
+  const float sin_theta = sqrt_for_hit(fmaf(-cos_theta, cos_theta, 1.0f));
   const float phi = kTwoPi * x2;
   float sphi, cphi;
   sincos_spec(phi, sphi, cphi);
@@ -358,6 +359,9 @@ __device__ __forceinline__ SphereHit scan_spheres_coop(const float4 *__restrict_
   rd.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.x)));
   rd.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.y)));
   rd.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(d.z)));
+  // lanes beyond the last ray work on a NaN origin: every test below fails for them (q and dn are NaN, "0 <= NaN" is
+  // false, a NaN key is never below the best one), which spares the loop a select per sphere
+  ro.x = has_ray ? ro.x : __uint_as_float(0x7fc00000u);
   uint32_t key = kNoHitKey;
   int slot = -1;
   const uint32_t n = n_sph_pad - kSphBatch;  // records that can hit (the tail records never do)
@@ -368,10 +372,10 @@ __device__ __forceinline__ SphereHit scan_spheres_coop(const float4 *__restrict_
     const float nx = ro.x - g.x, ny = ro.y - g.y, nz = ro.z - g.z;
     const float dn = fmaf(rd.z, nz, fmaf(rd.y, ny, rd.x * nx));
     const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
-    const unsigned long long cand = __builtin_amdgcn_fcmpf(has_ray ? fminf(q, -dn) : -1.0f, 0.0f, 3 /* OGE */);
+    const unsigned long long cand = __builtin_amdgcn_fcmpf(fminf(q, -dn), 0.0f, 3 /* OGE */);
     if (cand != 0ull) {
       const uint32_t k = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;
-      const bool take = has_ray & (k < key);
+      const bool take = k < key;
       slot = take ? static_cast<int>(j) : slot;
       key = take ? k : key;
     }
