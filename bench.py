@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend (gloo = 1-GPU rehearsal via host)")
     ap.add_argument("--force-comm", action="store_true",
                     help="rehearsal on one GPU: run the N = 1 job through a one-rank communicator (rt_comm_init), as N > 1 does")
+    ap.add_argument("--comm-timeout", type=float, default=90.0,
+                    help="N > 1: seconds the pre-flight launch's RCCL gather may take before the bench falls back to torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the one-frame-per-launch and 80-slot legs (profiling)")
     ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_S, help="minimum timed window of a leg")
@@ -150,6 +152,8 @@ def main():
         from rsraytracingv3_amd.distributed import TileParallelRenderer
         gather_path = "rt_comm_init: one-rank communicator (rehearsal)"
         tiles = TileParallelRenderer(dev, W, H, args.strip_rows)
+        if not tiles.preflight(conn, args.comm_timeout):
+            raise SystemExit("bench.py: the one-rank pre-flight launch did not complete")
     if world > 1:
         from rsraytracingv3_amd.distributed import TileParallelRenderer, TorchTileRenderer
         # production: the gather inside librt355 over RCCL; a gloo rehearsal (ranks sharing one GPU, which RCCL
@@ -170,6 +174,18 @@ def main():
                     gather_path = "torch.distributed.gather (TorchTileRenderer) — rt_comm_init failed on another rank"
                 print("bench.py rank %d: %s" % (rank, gather_path), file=sys.stderr, flush=True)
                 tiles = TorchTileRenderer(dev, W, H, args.strip_rows)
+            else:
+                # pre-flight: one launch and its gather under a watchdog — an exchange that never completes must cost the
+                # measurement its transport, not its life
+                stuck = 0.0 if tiles.preflight(conn, args.comm_timeout) else 1.0
+                flag = torch.tensor([stuck], device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if flag.item() > 0.0:
+                    tiles.abort()
+                    gather_path = ("torch.distributed.gather (TorchTileRenderer) — the RCCL gather of the pre-flight launch did not "
+                                   "complete within %.0f s on %s" % (args.comm_timeout, "this rank" if stuck else "another rank"))
+                    print("bench.py rank %d: %s" % (rank, gather_path), file=sys.stderr, flush=True)
+                    tiles = TorchTileRenderer(dev, W, H, args.strip_rows)
         else:
             gather_path = "torch.distributed.gather over %s, staged through host memory (rehearsal)" % args.backend
             tiles = TorchTileRenderer(dev, W, H, args.strip_rows)

@@ -164,6 +164,12 @@ RT355_API int rt_set_partition(rt_context *ctx, uint32_t rank, uint32_t world, u
 RT355_API int rt_comm_get_unique_id(void *id128);
 RT355_API int rt_comm_init(rt_context *ctx, const void *id128, uint32_t rank, uint32_t world, uint32_t strip_rows);
 RT355_API int rt_comm_destroy(rt_context *ctx);
+/* Watchdog for the exchange: rt_comm_idle sets *idle to 1 when everything queued on the context (renders, resolves, the
+ * gathers on the communication stream) has completed, 0 otherwise, without waiting.  rt_comm_abort gives up on an
+ * exchange that does not complete (a peer that never posted its side): ncclCommAbort, then the context is a
+ * single-GPU context again (as after rt_comm_destroy, which would wait for the exchange forever). */
+RT355_API int rt_comm_idle(rt_context *ctx, int *idle);
+RT355_API int rt_comm_abort(rt_context *ctx);
 /* The whole frame, sRGB8 texels, height x width x 4 bytes: on one GPU the same as rt_read_rgba8; with a
  * communicator only on rank 0 (other ranks: RT_ERR_INVALID_ARGUMENT; their rt_read_rgba8 still returns their rows). */
 RT355_API int rt_read_frame_rgba8(rt_context *ctx, void *dst, size_t bytes);

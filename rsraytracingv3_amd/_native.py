@@ -70,6 +70,8 @@ SIGNATURES = {
     "rt_comm_get_unique_id": (_i, [_vp]),
     "rt_comm_init": (_i, [_vp, _vp, _u32, _u32, _u32]),
     "rt_comm_destroy": (_i, [_vp]),
+    "rt_comm_idle": (_i, [_vp, _vp]),
+    "rt_comm_abort": (_i, [_vp]),
     "rt_read_frame_rgba8": (_i, [_vp, _vp, _sz]),
     "rt_assemble_strips": (_i, [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rt_set_accum_mode": (_i, [_vp, _i]),

@@ -112,6 +112,16 @@ class Device:
     def comm_destroy(self):
         self.call("rt_comm_destroy")
 
+    def comm_idle(self) -> bool:
+        """rt_comm_idle: has everything queued on the context (renders, resolves, gathers) completed?  Never waits."""
+        idle = C.c_int(0)
+        self.call("rt_comm_idle", C.byref(idle))
+        return bool(idle.value)
+
+    def comm_abort(self):
+        """rt_comm_abort: give up on an exchange that does not complete; the context is single-GPU again."""
+        self.call("rt_comm_abort")
+
     def read_frame_rgba8(self, width: int, height: int) -> np.ndarray:
         """The assembled frame (rank 0 of a communicator, or the only GPU)."""
         out = np.empty((height, width, 4), np.uint8)

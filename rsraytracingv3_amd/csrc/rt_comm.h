@@ -24,6 +24,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional: rt_comm_abort falls back to leaking the communicator
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -72,6 +73,7 @@ inline const RcclApi &rccl_api(std::string *why) {
       a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
       a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
       a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+      a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(h, "ncclCommAbort"));
       a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
       a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
       a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));

@@ -742,6 +742,37 @@ int rt_comm_destroy(rt_context *ctx) {
   return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
 }
 
+int rt_comm_idle(rt_context *ctx, int *idle) {
+  if (!ctx || !idle) return RT_ERR_INVALID_ARGUMENT;
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  hipError_t e = hipStreamQuery(ctx->stream);  // the renders of the internal streams are joined on this one
+  if (e == hipSuccess && ctx->comm_stream) e = hipStreamQuery(ctx->comm_stream);
+  if (e != hipSuccess && e != hipErrorNotReady) return fail(ctx, RT_ERR_DEVICE, "rt_comm_idle: %s", hipGetErrorString(e));
+  (void)hipGetLastError();  // hipErrorNotReady is not an error
+  *idle = e == hipSuccess ? 1 : 0;
+  return RT_OK;
+}
+
+int rt_comm_abort(rt_context *ctx) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (!ctx->comm) return RT_OK;
+  (void)hipSetDevice(ctx->device);
+  std::string why;
+  const RcclApi &api = rccl_api(&why);
+  // no synchronisation first: the point is to get rid of an exchange that does not finish
+  if (api.ok() && api.CommAbort) (void)api.CommAbort(ctx->comm);
+  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipGetLastError();
+  ctx->comm = nullptr;
+  ctx->comm_world = 0;
+  ctx->comm_rank = 0;
+  ctx->gather_pending[0] = ctx->gather_pending[1] = false;
+  ctx->rank = 0;
+  ctx->world = 1;
+  return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
+}
+
 int rt_read_frame_rgba8(rt_context *ctx, void *dst, size_t bytes) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!dst) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_read_frame_rgba8: dst is NULL");

@@ -203,5 +203,21 @@ class TileParallelRenderer:
             return self.rt.read_frame_rgba8(self.width, self.height)
         return None
 
+    def preflight(self, connection, timeout_s: float = 90.0) -> bool:
+        """One launch and its gather, polled instead of waited for: False when the exchange has not completed after
+        ``timeout_s`` (a peer that never posts its side would otherwise hang every later call).  Every rank must call
+        it; the caller agrees on the outcome across ranks and, on failure, calls ``abort`` everywhere."""
+        import time
+        self.render(connection, (0.0, 0.0), 0)
+        deadline = time.monotonic() + timeout_s
+        while not self.rt.comm_idle():
+            if time.monotonic() > deadline:
+                return False
+            time.sleep(0.005)
+        return True
+
+    def abort(self):
+        self.rt.comm_abort()
+
     def close(self):
         self.rt.comm_destroy()

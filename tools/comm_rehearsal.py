@@ -70,12 +70,30 @@ for accum in (N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32):
     if rank == 0:
         frame = dev.read_frame_rgba8(W, H)
         ok = ok and np.array_equal(frame, ref.rgba8)
+# the watchdog calls: everything queued has completed after a sync; after rt_comm_abort the context is a single-GPU
+# context again and renders the whole frame by itself
+if not dev.comm_idle():
+    ok = False
+    print("rank %d: rt_comm_idle says busy after rt_sync" % rank, flush=True)
 if world > 1:
     flag = [ok]
     dist.broadcast_object_list(flag, src=0)
     ok = flag[0]
     dist.barrier()
-dev.comm_destroy()
+if world == 1:
+    dev.comm_abort()
+    target = RenderTarget.new(dev, (W, H))
+    conn.last_size = (0, 0)
+    conn.update_buffers((W, H), scene, (0.0, 0.0))
+    conn.frame_data.jitter, conn.frame_data.progressive_count = (float(jit[0, 0]), float(jit[0, 1])), 0
+    conn.draw()
+    dev.sync()
+    alone = oracle.render(objects, count, cfg, jit[0], 0, sky, rnd, want_hits=False)
+    if not np.array_equal(target.read_rgba8(), alone.rgba8):
+        ok = False
+        print("after rt_comm_abort the single-GPU frame differs from the oracle", flush=True)
+else:
+    dev.comm_destroy()
 dev.close()
 if world > 1:
     dist.destroy_process_group()
