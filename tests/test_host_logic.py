@@ -129,3 +129,25 @@ def test_random_scene_follows_reference_distributions():
     emissive = np.mean([o.material.emission_strength > 0 for o in spheres])
     assert 0.05 < rough0 < 0.45 and 0.02 < emissive < 0.4
     assert s.camera.position == (55.0, 65.0, 55.0) and s.reflection_limit == 3
+
+
+def test_trace_union_counts_shared_device_time_once(tmp_path):
+    """tools/trace_union.py: two overlapping dispatches and one apart -> union of the intervals, not their sum."""
+    import os
+    import subprocess
+    import sys
+    d = tmp_path / "stats"
+    d.mkdir()
+    rows = ['"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id",'
+            '"Start_Timestamp","End_Timestamp"']
+    for k, (s, e, name) in enumerate([(1000, 3000, "render_blocks<2, 7, true>"), (2000, 4000, "render_blocks<2, 7, true>"),
+                                      (10000, 11000, "render_blocks<2, 7, true>"), (0, 99999, "resolve_batch_kernel")]):
+        rows.append('"KERNEL_DISPATCH","Agent 2",1,0,1,%d,1,"%s",%d,%d,%d' % (k, name, k, s, e))
+    (d / "x_kernel_trace.csv").write_text("\n".join(rows) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "trace_union.py"), str(d)], capture_output=True, text=True,
+                         check=True).stdout
+    assert "last 3 dispatches" in out
+    assert "mean kernel duration          0.0017 ms" in out          # (2000 + 2000 + 1000) / 3 ns
+    assert "device time per launch        0.0013 ms" in out          # union 3000 + 1000 = 4000 / 3 ns
+    assert "kernels running at once       1.25" in out
