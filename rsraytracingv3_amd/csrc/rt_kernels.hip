@@ -1017,8 +1017,8 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
 #ifndef RT_STREAM_MIN_TILES
 #define RT_STREAM_MIN_TILES 0  // auto rule: sample-only launches of this many 8x8 tiles are streamed; 0 = never (A/B on one device,
                                // 1080p, frames per launch 2 / 4 / 8 / 16: streamed 26.4 / 31.6 / 33.6 / 34.2 Grays/s against 30.4 /
-                               // 32.8 / 34.1 / 34.0 re-packed — full waves make the wave-wide square-root skip of the scan fire
-                               // rarely, which costs what the fuller lanes gain)
+                               // 32.8 / 34.1 / 34.0 re-packed — fuller waves take the root for 18 % of the spheres they test
+                               // instead of 10 %, shade with every branch taken, and the queue costs instructions of its own)
 #endif
 #ifndef RT_STREAM_WAVES
 #define RT_STREAM_WAVES 6  // waves per SIMD the bounce pass is budgeted for
