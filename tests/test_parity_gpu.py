@@ -387,6 +387,26 @@ def test_streamed_shape_primary_pass_queue_bounce_pass(device, refill_min, tile_
         device.set_option(N.RT_OPT_TILE_CHUNK, 2)
 
 
+def test_streamed_shape_under_a_partition_and_its_fall_back(device):
+    """Variant 4 on rank 1's strips of a 3-way partition (the strip mapping of path_begin, the queue sized for the
+    rank's rows) equals the sequential frames; a launch that is not sample-only (one frame at a time, nothing in flight)
+    asked for variant 4 takes the re-packing shape instead."""
+    scene = cases.headline_scene(12)
+    sky, rnd = cases.inputs(256, 128)
+    jit = [(0.1, -0.2), (-0.33, 0.27), (0.45, 0.05), (-0.49, -0.49)]
+    (seq, bat), st = _batch_vs_sequential(device, scene, (250, 203), sky, rnd, jit, 0, N.RT_ACCUM_SRGB8, 4, partition=(1, 3, 8))
+    assert st.last_variant == 4 and st.last_batch == 4
+    assert np.array_equal(seq[0], bat[0]) and np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32))
+    device.set_option(N.RT_OPT_INFLIGHT, 1)
+    try:
+        outs, st1 = run_gpu(device, scene, (96, 64), sky, rnd, (0.0, 0.0), variant=4)
+        assert st1.last_variant == 3
+        assert_frame_equal(outs[0], run_oracle(scene, (96, 64), sky, rnd, (0.0, 0.0)))
+    finally:
+        device.set_option(N.RT_OPT_INFLIGHT, 4)
+        device.set_partition(0, 1, 8)
+
+
 def test_batch_launch_restarting_accumulation_and_oracle(device):
     """A batch whose first frame has progressive_count 0 (history ignored) against the oracle's frame chain,
     under a 3-way strip partition (rank 1's rows)."""
