@@ -1508,11 +1508,11 @@ int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfi
   int variant = lc.variant;
   if (variant < 0) {
     // Measured on MI355X (tools/variant_sweep.py): the re-packing shape wins every multi-frame
-    // launch down to a rank's eighth of a 1080p frame, and single-frame launches from about half a 1080p frame up;
+    // launch down to a rank's eighth of a 1080p frame, and single-frame launches from about three quarters of a 1080p frame up;
     // scenes with hundreds of spheres (grid or not) and small single frames are fastest as plain tiles.  The
     // resident-wave shape (2) is never the fastest since the primary-ray culling, which it cannot use; selectable.
     // The streamed shape (4) only draws level from 16 frames per launch up; selectable.
-    const uint64_t enough = fp.batch > 1u ? 20000ull : 12000ull;
+    const uint64_t enough = fp.batch > 1u ? 20000ull : 24000ull;  // single frames: a whole 1080p frame (32 400 tiles) re-packs, half of one renders as tiles
     variant = (sc.n_sph_pad > 128u || tiles < enough || sc.grid.enabled) ? 0 : 3;
 #if RT_STREAM_MIN_TILES
     if (variant == 3 && tiles >= RT_STREAM_MIN_TILES && sample_only(fp)) variant = 4;
