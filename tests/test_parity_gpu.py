@@ -640,3 +640,36 @@ def test_branch_free_root_gives_the_exact_hit_key(device):
     assert same.all(), "%d of %d keys differ, e.g. dn=%r q=%r" % ((~same).sum(), n, dn[~same][:3], q[~same][:3])
     assert (fast[q >= np.float32(2.0 ** -96)] == exact[q >= np.float32(2.0 ** -96)]).all()
     assert int(((exact < no_hit) & (q < np.float32(2.0 ** -96))).sum()) > 1000, "the sweep must reach acceptable keys with tiny q"
+
+
+@pytest.mark.parametrize("variant", [0, 3])
+def test_degenerate_spheres_around_ray_origins(device, variant):
+    """Discriminants far below 2^-96, where the scans' root is only bounded, not correctly rounded (sqrt_for_hit): spheres
+    of radius 1e-17 .. 1e-9 centred exactly at the camera, a hair in front of it along the axes and the view direction,
+    and at the points where a big sphere's bounce rays start — against the oracle's IEEE roots, with the hit indices
+    compared per segment."""
+    from rsraytracingv3_amd.scene import Camera, Geometry, Material, Object, Scene
+    cam = (1.5, 2.0, -6.0)
+    objs = [Object("big", Material((0.9, 0.8, 0.7), (0, 0, 0), 0.0, 0.5, 0.0), Geometry.sphere((1.5, 2.0, 4.0), 3.0)),
+            Object("rough", Material((0.5, 0.9, 0.6), (1, 1, 0), 2.0, 0.5, 0.6), Geometry.sphere((-4.0, 1.0, 6.0), 2.5))]
+    k = 0
+    for radius in (1e-17, 1e-15, 1e-13, 1e-11, 1e-9):
+        for off in ((0, 0, 0), (1e-12, 0, 0), (0, 0, 2.0 ** -10), (0, 3e-8, 1e-7), (0, 0, 1e-3), (2.0 ** -12, 0, 2.0 ** -12)):
+            c = tuple(float(np.float32(a) + np.float32(b)) for a, b in zip(cam, off))
+            objs.append(Object("dust%d" % k, Material((0.3, 0.3, 0.9), (0, 1, 1), 1.0, 0.5, 0.3), Geometry.sphere(c, radius)))
+            k += 1
+    # dust on the big sphere's surface, where mirror bounces start 0.001 above it
+    for a in np.linspace(-0.6, 0.6, 9):
+        p = (1.5 + 3.0 * np.sin(a), 2.0, 4.0 - 3.0 * np.cos(a))
+        n = (np.sin(a), 0.0, -np.cos(a))
+        c = tuple(float(np.float32(pi + 0.001 * ni)) for pi, ni in zip(p, n))
+        objs.append(Object("dust%d" % k, Material((0.9, 0.2, 0.2), (1, 0, 0), 3.0, 0.5, 0.0), Geometry.sphere(c, 1e-12)))
+        k += 1
+    objs.append(Object("ground", Material((0.5, 0.5, 0.5), (0, 0, 0), 0.0, 0.5, 0.5), Geometry.plane((0, -1.0, 0), (0, 1, 0), 1e5)))
+    scene = Scene(objects=objs, camera=Camera(cam, (0.0, 0.0, 0.0), 60.0), reflection_limit=6)
+    sky, rnd = cases.inputs(128, 64)
+    for size, jitter in (((65, 65), (0.0, 0.0)), ((128, 96), (0.25, -0.125))):  # 65x65, no jitter: a pixel centre on the view axis
+        outs, st = run_gpu(device, scene, size, sky, rnd, jitter, max_objects="live", variant=variant)
+        ref = run_oracle(scene, size, sky, rnd, jitter, max_objects="live")
+        assert_frame_equal(outs[0], ref)
+        assert st.last_segments == int(ref.segments.sum())
