@@ -77,6 +77,9 @@ constexpr int kTile = 8;  // 8x8 pixels per tile / wave
                        // 32.5 / 33.1 at 5, 1 wave 32.7 / 30.5, 8 waves 27.0 / 27.5 — hence 2 waves, and the register
                        // budget by launch kind
 #endif
+#ifndef RT_PACK_HITS
+#define RT_PACK_HITS 1  // re-packing shape: pack the paths that hit between the scan and the shading (0: after the shading)
+#endif
 #ifndef RT_XCHG_PATHS
 #define RT_XCHG_PATHS ((RT_BLOCK_NW - 1) * 64)  // re-packing needs the paths to fit one wave fewer
 #endif
@@ -705,6 +708,48 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
   return alive;
 }
 
+// The ray_intersect half of one iteration for a whole wave (every lane calls it): the sphere scan the wave's state asks
+// for — the tile's culled list for primary rays, the cooperative scan at <= 32 live rays, the full scan otherwise — and
+// the planes.  `alive` lanes get their Hit (obj -1 = miss); the others get a miss.  Used by render_blocks, which packs the
+// paths that HIT before it shades them.
+template <bool LEAN>
+__device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FrameParams &fp, const Path &s, bool alive,
+                                              const unsigned long long *__restrict__ primary_mask,
+                                              const unsigned long long *__restrict__ primary_mask2 RT_PH_PARAMS) {
+  Hit h;
+  h.t = 0.0f;
+  h.obj = -1;
+  h.slot = -1;
+  h.plane = false;
+  const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
+  const uint32_t n_live = static_cast<uint32_t>(__popcll(live));
+  if (n_live == 0u) return h;
+  if (primary_mask != nullptr) {  // wave-uniform: all live lanes carry primary rays of one tile
+    if (alive) {
+      const SphereHit sh = scan_spheres_listed(sv.sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
+      if (!LEAN && fp.cull_check) {  // self-check frame: the full scan must agree
+        const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
+        if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
+      }
+      h = finish_hit(sv, sh, s.o, s.d);
+    }
+    RT_PH_MARK(0)
+  } else if (n_live <= 32u) {
+    const SphereHit sh = scan_spheres_coop(sv.sph, sv.n_sph_pad, s.o, s.d, alive, live, n_live);
+    RT_PH_MARK(2)
+    if (alive) h = finish_hit(sv, sh, s.o, s.d);
+    RT_PH_MARK(3)
+  } else {
+    if (alive) {
+      const SphereHit sh = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
+      RT_PH_MARK(1)
+      h = finish_hit(sv, sh, s.o, s.d);
+    }
+    RT_PH_MARK(3)
+  }
+  return h;
+}
+
 // frag.hlsl:60-65 + the Rgba8UnormSrgb store (D13).  At progressive_count 0 the history weight
 // is exactly 0, so the history is not read.
 template <bool DEFER_SKY = false, bool LEAN = false>
@@ -911,6 +956,86 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   // stores, ~150 instructions) together with the other finished lanes when the lane is about to be
   // re-used or the wave ends, not one partial-wave call per bounce.
   bool finished = false;
+#if RT_PACK_HITS
+  // Every bounce: scan -> the paths that missed end -> the workgroup counts the paths that HIT and packs them into fewer
+  // waves when they fit -> shade.  Packing between the scan and the shading (instead of after the shading) spares the
+  // surplus wave its shading pass: the misses, a third of the rays of a bounce, have left by then.
+  for (;;) {
+    Hit h = path_scan_wave<LEAN>(sv, fp, s, alive, primary_mask, primary_mask2 RT_PH_ARGS);
+    primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
+    if (alive && h.obj < 0) {  // frag.hlsl:14-17: a miss ends the path (its skybox texel is fetched in path_end)
+      (void)path_shade<RT_DEFER_SKY_BLOCKS, LEAN>(sv, fp, s, h, 0.0f, 0.0f, 0.0f);
+      alive = false;
+      finished = true;
+    }
+    unsigned int *counts = wave_count[iters & 1u];
+    iters += 1u;
+    const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
+    if (lane == 0) counts[wave] = static_cast<uint32_t>(__popcll(live));
+    __syncthreads();
+    RT_PH_MARK(4)
+    uint32_t total = 0, before = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const uint32_t c = (static_cast<uint32_t>(w) < live_waves) ? counts[w] : 0u;
+      before += (static_cast<uint32_t>(w) < wave) ? c : 0u;
+      total += c;
+    }
+    if (total == 0u) break;
+    const uint32_t need = (total + 63u) >> 6;
+    if (need < live_waves && total <= kXchgPaths) {
+      // pack: path number = paths in lower waves + live lanes below this one; the hit travels with the path
+      if (alive) {
+        const uint32_t r = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+        float4 *q = xchg + 5u * r;
+        q[0] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
+        q[1] = make_float4(s.d.y, s.d.z, s.energy.x, s.energy.y);
+        q[2] = make_float4(s.energy.z, s.result.x, s.result.y, s.result.z);
+        q[3] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p | (s.seg << 26)));
+        q[4] = make_float4(h.t, __int_as_float(h.slot), __int_as_float(h.obj), __uint_as_float(h.plane ? 1u : 0u));
+      }
+      if (finished) {  // the lane's registers are about to change hands
+        path_end<RT_DEFER_SKY_BLOCKS, LEAN>(fp, s);
+        seg_total += s.seg;
+        finished = false;
+      }
+      __syncthreads();
+      if (wave >= need) break;  // surplus wave: its paths now live in a lower wave
+      const uint32_t r = wave * 64u + lane;
+      alive = r < total;
+      if (alive) {
+        const float4 *q = xchg + 5u * r;
+        const float4 a = q[0], b = q[1], c = q[2], e = q[3], g = q[4];
+        s.o = mk3(a.x, a.y, a.z);
+        s.d = mk3(a.w, b.x, b.y);
+        s.energy = mk3(b.z, b.w, c.x);
+        s.result = mk3(c.y, c.z, c.w);
+        s.rng = Rng{e.x, e.y, e.z};
+        const uint32_t packed = __float_as_uint(e.w);
+        s.p = packed & 0x03ffffffu;
+        s.seg = packed >> 26;
+        s.rough = 0;
+        h.t = g.x;
+        h.slot = __float_as_int(g.y);
+        h.obj = __float_as_int(g.z);
+        h.plane = __float_as_uint(g.w) != 0u;
+      }
+      live_waves = need;
+      // No barrier here: the exchange buffer is next written after the next count barrier, which the
+      // surviving waves only pass once their reads above have completed.
+      RT_PH_MARK(5)
+    }
+    if (alive) {  // shade the hit; the first random() texel is requested here, by the lanes that still carry a path
+      const float x1 = fp.rnd[rng_texel(fp, s.rng)];
+      alive = path_shade<RT_DEFER_SKY_BLOCKS, LEAN>(sv, fp, s, h, x1, 0.0f, 0.0f);
+      rough_total += s.rough & 0x7fffffffu;
+      s.rough &= 0x80000000u;
+      finished |= !alive;
+    }
+    RT_PH_MARK(3)
+  }
+#else
   for (;;) {
     {
       const bool was = alive;
@@ -974,6 +1099,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
       RT_PH_MARK(5)
     }
   }
+#endif
   RT_PH_MARK(5)
   if (finished) {
     path_end<RT_DEFER_SKY_BLOCKS, LEAN>(fp, s);
@@ -1562,7 +1688,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
                        fp, static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 3) {
     const dim3 blocks((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW, tiles_y, fp.batch);  // x: tile columns, y: tile rows, z: frames
-    const size_t bytes = lds_image + static_cast<size_t>(kXchgPaths) * 4 * sizeof(float4);
+    const size_t bytes = lds_image + static_cast<size_t>(kXchgPaths) * (RT_PACK_HITS ? 5 : 4) * sizeof(float4);
     const bool lean = sample_only(fp);
     if (fp.batch > 1u && lean) {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
