@@ -901,13 +901,14 @@ __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FramePar
 }
 
 // Block-compacting tile kernel.  A workgroup of NW waves starts NW 8x8 tiles (one pixel per lane).
-// After every bounce the surviving paths of the whole workgroup are counted (ballot + popcount per
-// wave, summed through LDS); as soon as they fit into fewer waves they are packed through an LDS
-// exchange buffer (64 B of path state each) into waves 0..k-1 and the surplus waves END — gfx950's
-// s_barrier drops ended waves from its count (tools/microbench/barrier_exit.hip), and their
-// registers and wave slots go to the next workgroup.  Path lengths vary 1..R, so without this most
-// of a tile's later scans run with a handful of live lanes.  Pixel results do not depend on which
-// lane finishes a path, so the frame stays bit-identical.
+// Every bounce, after the scan, the paths of the whole workgroup that HIT something are counted (ballot +
+// popcount per wave, summed through LDS); as soon as they fit into fewer waves they are packed through an
+// LDS exchange buffer (80 B each: path state + the hit) into waves 0..k-1 and the surplus waves END — gfx950's
+// s_barrier drops ended waves from its count (tools/microbench/barrier_exit.hip), and their registers and
+// wave slots go to the next workgroup — then the hits are shaded.  Path lengths vary 1..R, so without this
+// most of a tile's later scans run with a handful of live lanes.  Pixel results do not depend on which
+// lane finishes a path, so the frame stays bit-identical.  (RT_PACK_HITS 0: count and pack the survivors after
+// the shading instead.)
 template <int NW, int WAVES, bool LEAN>
 __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_all[];
