@@ -109,6 +109,8 @@ def run(cases=100, first=0):
                   % (seed, len(scene.objects), size, scene.reflection_limit, variant, slots, st.last_cull_mismatches, st.grid_cells),
                   flush=True)
         grids += st.last_stage == 3
+        if (seed - first + 1) % 1000 == 0:  # a long soak must not look hung to the box's watchdog
+            print("  ... %d cases, %d mismatching so far" % (seed - first + 1, bad), flush=True)
     dev.set_option(N.RT_OPT_CULL, 1)
     dev.set_option(N.RT_OPT_GRID_MIN, 129)
     dev.close()
