@@ -1581,6 +1581,8 @@ __global__ void math_binary_kernel(int op, const float *a, const float *b, float
     y[i] = __uint_as_float(__float_as_uint(-a[i] - sqrt_for_hit(b[i])) - kEpsBits);
   } else if (op == 4) {
     y[i] = __uint_as_float(__float_as_uint(-a[i] - sqrtf(b[i])) - kEpsBits);
+  } else if (op == 5) {  // the kernels' texel addressing: a = u, b = texture size (as a float)
+    y[i] = static_cast<float>(texel_index(a[i], b[i], b[i] - 1.0f));
   } else {
     y[i] = op == 0 ? atan2_spec(a[i], b[i]) : (op == 1 ? pow_spec(a[i], b[i]) : a[i] / b[i]);
   }

@@ -217,7 +217,14 @@ RT_HD uint32_t texel_index(float u, uint32_t size) {
 // registers.
 RT_HD uint32_t texel_index(float u, float size_f, float last_f) {
   float t = floorf(u * size_f);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the clamp as one v_med3_f32: the median of (t, 0, last) is fminf(fmaxf(t, 0), last) for every t including the
+  // infinities, and for a NaN the instruction returns the minimum of the other two operands, 0, as fmaxf(NaN, 0) does
+  // (tests/test_parity_gpu.py::test_device_math_bitwise)
+  t = __builtin_amdgcn_fmed3f(t, 0.0f, last_f);
+#else
   t = fminf(fmaxf(t, 0.0f), last_f);
+#endif
   return static_cast<uint32_t>(t);
 }
 

@@ -317,6 +317,18 @@ def test_device_math_bitwise(device):
     a = rs.normal(size=n).astype(np.float32)
     b = rs.normal(size=n).astype(np.float32)
     assert np.array_equal(dev_binary(2, a, b).view(np.uint32), (a / b).view(np.uint32)), "device divide not IEEE"
+    # texel addressing (connection.rs:164-174 nearest + clamp-to-edge): clamp(floor(u * size), 0, size - 1), NaN -> 0
+    u = rs.uniform(-0.5, 1.5, n).astype(np.float32)
+    u[:8] = [np.nan, np.inf, -np.inf, 0.0, -0.0, 1.0, np.nextafter(np.float32(1), np.float32(0)), 1e30]
+    size = rs.choice([1.0, 2.0, 600.0, 2048.0, 8192.0], n).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        t = np.floor(u * size)
+        want = np.where(np.isnan(t), np.float32(0), np.minimum(np.maximum(t, np.float32(0)), size - np.float32(1))).astype(np.float32)
+    assert np.array_equal(dev_binary(5, u, size), want), "texel index"
+    # ... and the oracle's own addressing on directions that land on those edge cases (u = 0.5 + atan2/2pi, v = 0.5 + asin/pi)
+    for d in ([0.0, 1.0, 0.0], [0.0, -1.0, 0.0], [0.0, 0.0, -1.0], [np.nan, 0.0, 1.0], [1e-30, 0.0, -1.0]):
+        i, j = oracle.probe_hdri_texel(np.array(d, np.float32), 2048, 1024)
+        assert 0 <= i < 2048 and 0 <= j < 1024
 
 
 def _batch_vs_sequential(device, scene, size, sky, rnd, jitters, first_pc, accum, variant, partition=(0, 1, 8)):
