@@ -151,3 +151,29 @@ def test_trace_union_counts_shared_device_time_once(tmp_path):
     assert "mean kernel duration          0.0017 ms" in out          # (2000 + 2000 + 1000) / 3 ns
     assert "device time per launch        0.0013 ms" in out          # union 3000 + 1000 = 4000 / 3 ns
     assert "kernels running at once       1.25" in out
+
+
+def test_committed_bench_line_keeps_the_contract():
+    """The JSON line bench.py printed on the GPU box (profiles/r02_bench_driver_flags.json, the driver's flags): every key
+    the bench contract names is there, with the types and relations it asks for."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r02_bench_driver_flags.json")) as f:
+        d = json.loads(f.read())
+    for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                      ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], kind), key
+    assert d["vs_baseline"] is None and d["unit"] == "Mrays/s" and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"] is None or r["traffic"] > 0
+    # value = segments / time: consistent with ms_per_step and the segments per pixel the line reports
+    px = 1920 * 1080
+    assert abs(d["value"] - d["config"]["segments_per_pixel"] * px / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
+    assert 0.0 < d["valu"]["frac"] < 1.0 and d["valu"]["peak"] == 157.3
