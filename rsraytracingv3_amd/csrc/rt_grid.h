@@ -29,6 +29,11 @@ struct GridBuild {
   std::vector<uint16_t> items;
 };
 
+// Cells per sphere the resolution aims at.  A/B on one device (tools/grid_density_sweep.sh, Grays/s at 128 / 256 / 1024
+// spheres): 2 cells per sphere 38.4 / 30.2 / 16.0, 1: 39.7 / 31.1 / 16.4, 0.5: 40.3 / 31.6 / 18.8, 0.35: 40.2 / 31.8 / 18.9,
+// 0.125: 40.2 / 31.4 / 18.2, 0.06: 39.2 / 28.7 / 16.7 — a lane's walk costs per cell it crosses (and lanes of a wave cross
+// different cells), a few more spheres per cell cost less.
+constexpr double kGridCellsPerSphere = 0.35;
 constexpr uint32_t kGridMaxDim = 64;
 constexpr uint32_t kGridMaxItems = 12288;          // u16 entries (24 KB)
 constexpr size_t kGridLdsBudget = 56u * 1024u;     // sphere records + cell_start + items
@@ -71,8 +76,8 @@ inline GridBuild build_grid(const std::vector<float4> &sph, size_t n_live, size_
   }
   double ext[3];
   for (int a = 0; a < 3; ++a) ext[a] = ghi[a] - glo[a];
-  // resolution: about two cells per sphere, cubic cells, at least one and at most kGridMaxDim per axis
-  double target_cells = 2.0 * static_cast<double>(n_live);
+  // resolution: kGridCellsPerSphere cells per sphere, cubic cells, at least one and at most kGridMaxDim per axis
+  double target_cells = kGridCellsPerSphere * static_cast<double>(n_live);
   for (int attempt = 0; attempt < 6; ++attempt, target_cells *= 0.5) {
     const double s = std::cbrt(ext[0] * ext[1] * ext[2] / target_cells);
     uint32_t n[3];
