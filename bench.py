@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--batch-inflight", type=int, default=1,
                     help="RT_OPT_BATCH_INFLIGHT: multi-frame launches in flight (1 = one at a time, the library default: kernel "
                          "times do not overlap; 2 = the next launch renders while this one resolves, +1..4 %% throughput)")
-    ap.add_argument("--grid-min", type=int, default=0, help="RT_OPT_GRID_MIN: spheres from which a scene gets the sphere grid (0 = library default 96)")
+    ap.add_argument("--grid-min", type=int, default=0, help="RT_OPT_GRID_MIN: spheres from which a scene gets the sphere grid (0 = library default 88)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive 1-spp frames per kernel launch (rt_render_frames, 1..64); 0 = 8 per GPU of the job, "
                          "so that a launch carries eight frames' worth of tiles whatever the partition")

@@ -271,7 +271,7 @@ enum {
                               (app.rs:208-254) and one 1080p frame leaves a fifth of the GPU idle during its
                               ramp-up and tail; the history is still updated strictly in frame order on the
                               context's stream.  1 = one launch at a time (kernel times do not overlap).     */
-  RT_OPT_GRID_MIN = 7,     /* scenes with at least this many spheres (default 96) get a uniform grid at the next
+  RT_OPT_GRID_MIN = 7,     /* scenes with at least this many spheres (default 88) get a uniform grid at the next
                               rt_set_scene: secondary rays then test the spheres of the cells they cross instead of
                               every sphere (ray.hlsl:97-107 scans linearly; the reference caps scenes at 80)       */
   RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 1): as RT_OPT_INFLIGHT,

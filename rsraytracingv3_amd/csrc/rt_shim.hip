@@ -118,8 +118,9 @@ struct rt_context {
   int batch_inflight = 1;  // RT_OPT_BATCH_INFLIGHT
   uint64_t prep_generation = 0;                 // bumped whenever prep_done is re-recorded
   uint64_t prep_seen[kMaxInflight] = {};        // generation each render stream has already waited for
-  int grid_min_spheres = 96;   // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid (A/B on one
-                               // device, Grays/s linear / grid: 64 spheres 40.2 / 33.2, 96: 41.7 / 42.1, 128: 33.6 / 38.3)
+  int grid_min_spheres = 88;   // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid (A/B on one
+                               // device, tools/grid_threshold_sweep.sh, Grays/s linear / grid: 64 spheres 40.2 / 32.4, 80: 47.5 /
+                               // 47.3, 88: 45.2 / 46.3, 96: 41.9 / 45.5, 128: 33.7 / 40.6)
   hipStream_t render_stream[kMaxInflight] = {};
   hipEvent_t prep_done = nullptr;  // (the renders and resolves are joined on the per-launch timing events)
   bool resolve_pending[kMaxInflight] = {};  // pipe_samples[i] has been written; its resolve is ev_resolved[resolve_slot[i]]

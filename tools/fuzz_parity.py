@@ -49,7 +49,7 @@ def random_case(seed):
 
 def grid_min_for(seed):
     """RT_OPT_GRID_MIN of a case: every third case forces the sphere grid on small scenes too."""
-    return 1 if seed % 3 == 1 else 96
+    return 1 if seed % 3 == 1 else 88
 
 
 def run(cases=100, first=0):
@@ -112,7 +112,7 @@ def run(cases=100, first=0):
         if (seed - first + 1) % 1000 == 0:  # a long soak must not look hung to the box's watchdog
             print("  ... %d cases, %d mismatching so far" % (seed - first + 1, bad), flush=True)
     dev.set_option(N.RT_OPT_CULL, 1)
-    dev.set_option(N.RT_OPT_GRID_MIN, 96)
+    dev.set_option(N.RT_OPT_GRID_MIN, 88)
     dev.close()
     print("fuzz: %d cases from seed %d (%d of them walked a sphere grid), %d mismatching" % (cases, first, grids, bad), flush=True)
     return bad
