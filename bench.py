@@ -82,6 +82,9 @@ def main():
                     help="RT_OPT_BATCH_INFLIGHT: multi-frame launches in flight (1 = one at a time, the library default: kernel "
                          "times do not overlap; 2 = the next launch renders while this one resolves, +1..4 %% throughput)")
     ap.add_argument("--grid-min", type=int, default=0, help="RT_OPT_GRID_MIN: spheres from which a scene gets the sphere grid (0 = library default 88)")
+    ap.add_argument("--dirmask", type=int, default=-1, help="RT_OPT_DIRMASK: 0 = secondary rays scan every sphere, 1 = direction-mask table (library default)")
+    ap.add_argument("--dirmask-k", type=int, default=0, help="RT_OPT_DIRMASK_K (0 = library default)")
+    ap.add_argument("--dirmask-cells", type=int, default=0, help="RT_OPT_DIRMASK_CELLS (0 = library default)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive 1-spp frames per kernel launch (rt_render_frames, 1..64); 0 = 8 per GPU of the job, "
                          "so that a launch carries eight frames' worth of tiles whatever the partition")
@@ -97,6 +100,12 @@ def main():
     ap.add_argument("--clock-warmup", type=float, default=CLOCK_WARMUP_S, help="seconds of untimed launches before timing")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = all)")
     args = ap.parse_args()
+
+    # stdout carries ONE JSON line: native libraries that print there (RCCL's version banner at communicator creation)
+    # are pointed at stderr for the duration of the run; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -140,6 +149,12 @@ def main():
     dev.set_option(N.RT_OPT_BATCH_INFLIGHT, args.batch_inflight)
     if args.grid_min > 0:
         dev.set_option(N.RT_OPT_GRID_MIN, args.grid_min)
+    if args.dirmask >= 0:
+        dev.set_option(N.RT_OPT_DIRMASK, args.dirmask)
+    if args.dirmask_k > 0:
+        dev.set_option(N.RT_OPT_DIRMASK_K, args.dirmask_k)
+    if args.dirmask_cells > 0:
+        dev.set_option(N.RT_OPT_DIRMASK_CELLS, args.dirmask_cells)
     target = RenderTarget.new(dev, (W, H))
     rt = RandomTexture(dev)
     rt.write(rnd)
@@ -160,19 +175,17 @@ def main():
         # refuses) gathers through torch.distributed and host memory instead
         gather_path = "rt_comm_init: RCCL send/recv inside librt355"
         if args.backend == "nccl":
+            from rsraytracingv3_amd.distributed import CommUnavailable
             try:
-                tiles = TileParallelRenderer(dev, W, H, args.strip_rows)
-                failed = 0.0
-            except Exception as exc:  # reported, never silent: the line says which transport carried the gather
-                gather_path = "torch.distributed.gather (TorchTileRenderer) — rt_comm_init FAILED on rank %d: %s" % (rank, exc)
-                failed = 1.0
-            flag = torch.tensor([failed], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)  # every rank takes the same path
-            if flag.item() > 0.0:
-                if failed == 0.0:
-                    tiles.close()
-                    gather_path = "torch.distributed.gather (TorchTileRenderer) — rt_comm_init failed on another rank"
+                # raises CommUnavailable on EVERY rank or on none (the ranks agree inside, before and after
+                # ncclCommInitRank): no rank can be left waiting in a collective the others skipped
+                tiles = TileParallelRenderer(dev, W, H, args.strip_rows, init_timeout_s=args.comm_timeout)
+            except CommUnavailable as exc:  # reported, never silent: the line says which transport carried the gather
+                gather_path = "torch.distributed.gather (TorchTileRenderer) — rt_comm_init unavailable: %s" % exc
                 print("bench.py rank %d: %s" % (rank, gather_path), file=sys.stderr, flush=True)
+                if exc.fatal:  # this rank's context is still inside ncclCommInitRank: nothing can be measured with it
+                    sys.stderr.flush()
+                    os._exit(3)
                 tiles = TorchTileRenderer(dev, W, H, args.strip_rows)
             else:
                 # pre-flight: one launch and its gather under a watchdog — an exchange that never completes must cost the
@@ -364,13 +377,15 @@ def main():
     b_alg = algorithmic_bytes(head["frame_px"] * steps, blk["seg"], blk["rough"])
     f_alg = algorithmic_flops(head["frame_px"] * steps, blk["seg"], n_objects)
     achieved = b_alg / k_sec / 1e9
-    # Measured HBM traffic and issue utilisation come from the committed PMC passes of THIS workload and launch
-    # shape (profiles/traffic_r02.json, collected by tools/profile_round.sh); for any other workload they are null.
-    traffic = traffic_resolve = issue_util = None
+    # Measured HBM traffic and issue utilisation are IMPORTED from the committed PMC passes (separate rocprofv3 --pmc
+    # runs cannot happen inside this process): quoted only when the profile was collected on THIS workload, this launch
+    # shape AND these kernel sources (sha256 over csrc/ + include/, recorded by tools/pmc_summary.py); null otherwise.
+    traffic = traffic_resolve = issue_util = traffic_source = None
     workload_key = {"width": W, "height": H, "objects": n_objects, "bounces": args.bounces, "sky_width": args.sky, "n_gpus": world}
-    for name in ("traffic_r02.json",):
+    source_now = N.kernel_source_hash()
+    for name in ("traffic_r03.json", "traffic_r02.json"):
         tpath = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(tpath):
+        if not os.path.exists(tpath) or traffic is not None:
             continue
         try:
             with open(tpath) as f:
@@ -379,14 +394,23 @@ def main():
             continue
         prof_key = dict(prof.get("workload_key", {}))
         prof_key.pop("frames_per_launch", None)  # the profile's launches carried 8 frames; traffic is taken per frame
-        if prof_key == workload_key and B > 1:
-            # per launch of THIS run: the profile's bytes per frame x the frames an average launch of the block carried
-            frames_per_launch = float(steps) / launches
-            per_frame = prof.get("render_kernel", {}).get("hbm_bytes_per_frame")
-            traffic = round(per_frame * frames_per_launch, 1) if per_frame else None
-            per_frame = prof.get("resolve_kernel", {}).get("hbm_bytes_per_frame")
-            traffic_resolve = round(per_frame * frames_per_launch, 1) if per_frame else None
-            issue_util = prof.get("render_kernel", {}).get("valu_issue_util")
+        if prof_key != workload_key or B <= 1:
+            continue
+        if prof.get("kernel_source_sha256") != source_now:
+            traffic_source = {"file": "profiles/" + name, "used": False,
+                              "why": "collected on other kernel sources (sha256 %s..., this tree %s...)"
+                                     % (str(prof.get("kernel_source_sha256"))[:12], source_now[:12])}
+            continue
+        # per launch of THIS run: the profile's bytes per frame x the frames an average launch of the block carried
+        frames_per_launch = float(steps) / launches
+        per_frame = prof.get("render_kernel", {}).get("hbm_bytes_per_frame")
+        traffic = round(per_frame * frames_per_launch, 1) if per_frame else None
+        per_frame = prof.get("resolve_kernel", {}).get("hbm_bytes_per_frame")
+        traffic_resolve = round(per_frame * frames_per_launch, 1) if per_frame else None
+        issue_util = prof.get("render_kernel", {}).get("valu_issue_util")
+        traffic_source = {"file": "profiles/" + name, "used": True, "kernel_source_sha256": source_now[:16],
+                          "how": "imported, not measured in this run: separate rocprofv3 --pmc passes of this workload on these "
+                                 "kernel sources (tools/profile_round.sh), bytes per frame x frames per launch of this run"}
     out = {
         "metric": "Mrays/s at 1920x1080, 64 spheres, 8 bounces",
         "value": round(value, 2),
@@ -426,8 +450,11 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "achieved_basis": "algorithmic bytes (SURVEY.md 8d: 8 B/pixel + 16 B/segment + 8 B/rough hit) / HIP-event kernel time",
             "traffic": traffic,
             "traffic_resolve_kernel": traffic_resolve,
+            "traffic_source": traffic_source,
+            "measured_gbs": round(traffic / (k_sec / launches) / 1e9, 2) if traffic else None,
             "kernel": kernel_name(head["stats"]),
             "avg_launch_ms": round(blk["kernel_ms"] / launches, 5),
             "launches_in_flight": args.batch_inflight if B > 1 else 4,
@@ -448,7 +475,7 @@ def main():
             "peak": VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(f_alg / k_sec / 1e12 / VALU_PEAK_TFLOPS, 5),
-            "issue_util": issue_util,
+            "issue_util": issue_util,  # imported with roofline.traffic (see traffic_source)
             "alg_flops_per_launch": round(f_alg / launches, 1),
             "kernel_mrays_per_s": round(blk["seg"] / k_sec / 1e6, 2),
             "scan_lane_occupancy": round(float(head["stats"].last_segments) / (64.0 * head["stats"].last_wave_iterations), 4)
@@ -493,7 +520,8 @@ def main():
         }
         # cross-check: the GPU counted the same number of segments for the frames of that launch
         out["cpu_baseline"]["segments_match_gpu"] = bool(args.cpu_rows <= 0 and first_seg == blk["seg_first_launch"])
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT355_ABI_VERSION 2
+#define RT355_ABI_VERSION 3
 #define RT355_API __attribute__((visibility("default")))
 
 typedef enum rt_status {
@@ -77,13 +77,16 @@ typedef struct rt_stats {
                                  walk the grid); render_blocks (variant 3): 10 * waves per workgroup + waves per SIMD
                                  its registers are budgeted for (27 multi-frame launches, 25 single frames); 40 for variant 4   */
   uint32_t grid_cells, grid_items; /* the current scene's sphere grid (0 = none: small scene, or not buildable) */
+  uint32_t dirmask_cells, dirmask_bins; /* the current scene's direction-mask table (RT_OPT_DIRMASK): cells and direction
+                                           bins per cell; 0 = none                                                    */
 } rt_stats;
 
 /* Device-side view of the context's buffers, for zero-copy consumers (RCCL gather,
  * interop).  All pointers are device addresses on the context's GPU and stay valid
  * until the next rt_resize / rt_set_partition / rt_set_outputs / rt_destroy. */
 typedef struct rt_device_buffers {
-  void *rgba8;          /* local_rows x width x 4 B, sRGB-encoded, alpha 255 */
+  void *rgba8;          /* local_rows x width x 4 B, sRGB-encoded, alpha 255 (with a communicator: the target the
+                           last launch wrote — the two targets alternate, so ask again after every launch) */
   void *rgbf32;         /* local_rows x width x 3 floats, or NULL            */
   void *segments;       /* local_rows x width x u32, or NULL                 */
   void *hits;           /* local_rows x width x reflection_limit x i32, or NULL */
@@ -161,13 +164,19 @@ RT355_API int rt_set_partition(rt_context *ctx, uint32_t rank, uint32_t world, u
  * results do not depend on the partition (the RNG state is per pixel, random.hlsl:1-2,45-47): the assembled frame
  * is bit-identical to the single-GPU frame. */
 #define RT355_COMM_ID_BYTES 128
+/* Can an RCCL be bound in this process?  RT_OK / RT_ERR_NOT_READY; never a collective, needs no GPU and no context.  The
+ * text (the library bound, or why each candidate failed) goes to why[0..why_cap) when given.  Hosts call it on every
+ * rank and agree on the outcome BEFORE any rank enters rt_comm_init: a rank that cannot load RCCL returns from
+ * rt_comm_init at once while the others would wait inside ncclCommInitRank for it. */
+RT355_API int rt_comm_available(char *why, size_t why_cap);
 RT355_API int rt_comm_get_unique_id(void *id128);
 RT355_API int rt_comm_init(rt_context *ctx, const void *id128, uint32_t rank, uint32_t world, uint32_t strip_rows);
 RT355_API int rt_comm_destroy(rt_context *ctx);
 /* Watchdog for the exchange: rt_comm_idle sets *idle to 1 when everything queued on the context (renders, resolves, the
  * gathers on the communication stream) has completed, 0 otherwise, without waiting.  rt_comm_abort gives up on an
  * exchange that does not complete (a peer that never posted its side): ncclCommAbort, then the context is a
- * single-GPU context again (as after rt_comm_destroy, which would wait for the exchange forever). */
+ * single-GPU context again.  rt_comm_destroy and rt_destroy wait for an exchange in flight for at most 20 s and then
+ * abort it the same way: no call of this interface waits forever on a peer. */
 RT355_API int rt_comm_idle(rt_context *ctx, int *idle);
 RT355_API int rt_comm_abort(rt_context *ctx);
 /* The whole frame, sRGB8 texels, height x width x 4 bytes: on one GPU the same as rt_read_rgba8; with a
@@ -219,7 +228,8 @@ RT355_API int rt_read_rgba8_rows(rt_context *ctx, uint32_t first_row, uint32_t n
 RT355_API int rt_read_rgbf32_rows(rt_context *ctx, uint32_t first_row, uint32_t n_rows, float *dst, size_t bytes);
 RT355_API int rt_read_segments(rt_context *ctx, uint32_t *dst, size_t bytes);
 RT355_API int rt_read_hits(rt_context *ctx, int32_t *dst, size_t bytes);
-/* Overwrite the sRGB8 history (e.g. to resume an accumulation); local rows. */
+/* Overwrite the sRGB8 history (e.g. to resume an accumulation); local rows.  With a communicator the copy waits for the
+ * gather that still sends from that buffer. */
 RT355_API int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes);
 
 RT355_API int rt_get_device_buffers(rt_context *ctx, rt_device_buffers *out);
@@ -274,6 +284,13 @@ enum {
   RT_OPT_GRID_MIN = 7,     /* scenes with at least this many spheres (default 88) get a uniform grid at the next
                               rt_set_scene: secondary rays then test the spheres of the cells they cross instead of
                               every sphere (ray.hlsl:97-107 scans linearly; the reference caps scenes at 80)       */
+  RT_OPT_DIRMASK = 9,      /* 1 (default): scenes of RT_OPT_DIRMASK_MIN .. 64 spheres (below the grid's threshold) get a table
+                              of candidate-sphere sets at the next rt_set_scene — [cell of the ray's origin][cube-map bin of
+                              its direction] -> 64-bit set — and secondary rays test only their set instead of every
+                              sphere (ray.hlsl:97-107 scans linearly); rebuilt only when the sphere records change; 0: off */
+  RT_OPT_DIRMASK_MIN = 10,  /* fewest spheres that get the table (default 12)                                            */
+  RT_OPT_DIRMASK_CELLS = 11,/* cells the table's grid aims at (default 4096; cubic cells, at most 64 per axis)           */
+  RT_OPT_DIRMASK_K = 12,    /* direction bins per cube-map face edge, 1..16 (default 8: 384 bins)                        */
   RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 1): as RT_OPT_INFLIGHT,
                               each launch staging its samples in a buffer of its own; the history is updated in frame
                               order on the context's stream.  2 hides the resolve pass and the gap between launches
@@ -293,6 +310,21 @@ typedef struct rt_grid_info {
 } rt_grid_info;
 RT355_API int rt_grid_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t min_spheres, rt_grid_info *info,
                                  uint32_t *cell_start, uint32_t cell_cap, uint16_t *items, uint32_t item_cap);
+
+/* The direction-mask table rt_set_scene builds for scenes of up to 64 spheres (RT_OPT_DIRMASK), exposed for inspection
+ * and for testing its sets without a GPU: host code only, the same entry function the device kernel runs.  spheres =
+ * n x {cx, cy, cz, r*r}; table gets nx*ny*nz*bins 64-bit sets, [cell][bin] (when table_cap suffices; call with a null
+ * table for the sizes).  info->enabled = 0 when the scene is not served.  rt_dirmask_lookup_host repeats a lane's lookup:
+ * *served = 0 when the ray is not served by the table (origin outside the near box, direction not a unit vector — the
+ * kernels then scan linearly), else *mask = the ray's candidate set (0 for a ray that misses the spheres' box). */
+typedef struct rt_dirmask_info {
+  uint32_t enabled, nx, ny, nz, k, bins;
+  float bmin[3], bmax[3], cell[3], inv_cell[3], near_min[3], near_max[3];
+} rt_dirmask_info;
+RT355_API int rt_dirmask_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t target_cells, uint32_t k,
+                                    rt_dirmask_info *info, uint64_t *table, size_t table_cap);
+RT355_API int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, const float *origin3,
+                                     const float *direction3, uint64_t *mask, int *served);
 
 /* Device self-test hooks used by the parity tests: evaluate the device build of the
  * specified math function over n host values (op: 0 sin 1 cos 2 tan 3 asin 4 log2

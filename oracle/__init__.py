@@ -51,6 +51,8 @@ def lib():
         L.rto_render.argtypes = [u8p, C.c_uint32, u8p, u8p, f32p, C.c_uint32, C.c_uint32, f32p, C.c_uint32,
                                  C.c_uint32, u8p, f32p, C.c_int, f32p, u8p, u32p, i32p, C.c_uint32, C.c_uint32,
                                  C.c_int]
+        L.rto_set_ray_dump.restype = None
+        L.rto_set_ray_dump.argtypes = [f32p]
         L.rto_probe_intersect.restype = C.c_int
         L.rto_probe_intersect.argtypes = [u8p, C.c_uint32, f32p, f32p, f32p]
         L.rto_probe_create_ray.restype = None
@@ -121,6 +123,22 @@ def render(objects: bytes, object_count: int, config112: bytes, jitter=(0.0, 0.0
     if rc != 0:
         raise RuntimeError("rto_render failed: %d" % rc)
     return Frame(out_f, out_8, out_s, out_h)
+
+
+def render_with_rays(objects: bytes, object_count: int, config112: bytes, *args, **kwargs):
+    """``render`` + the ray (origin, direction) of every executed iteration: (Frame, rays[h, w, reflection_limit, 6]),
+    NaN where an iteration did not run.  Diagnostic for tests of the product's culling structures."""
+    import struct
+    cfg = bytes(config112)
+    w, h = struct.unpack_from("<II", cfg, 100)
+    rlimit = struct.unpack_from("<I", cfg, 96)[0]
+    rays = np.full((h, w, max(rlimit, 1), 6), np.nan, np.float32)
+    lib().rto_set_ray_dump(_p(rays, C.c_float))
+    try:
+        frame = render(objects, object_count, config112, *args, **kwargs)
+    finally:
+        lib().rto_set_ray_dump(None)
+    return frame, rays
 
 
 def probe_intersect(objects: bytes, object_count: int, origin, direction):

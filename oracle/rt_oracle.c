@@ -331,10 +331,15 @@ static inline v3 shade(const Scene *sc, Rng *rng, Ray *ray, const Hit *hit) {
 
 /* frag.hlsl:32-46.  D1: the left operand ray.energy is read BEFORE shade()
  * updates it; result += energy*shade is fused (D15). */
-static inline v3 trace_ray_with_reflections(const Scene *sc, Rng *rng, Ray ray, uint32_t *segments, int32_t *hits) {
+static inline v3 trace_ray_with_reflections(const Scene *sc, Rng *rng, Ray ray, uint32_t *segments, int32_t *hits,
+                                            float *rays) {
   v3 result = V(0.0f, 0.0f, 0.0f);
   uint32_t n = 0;
   for (uint32_t i = 0; i < sc->config.reflection_limit; i += 1) {
+    if (rays) { /* diagnostic (rto_set_ray_dump): the ray this iteration intersects */
+      rays[6 * i] = ray.origin.x; rays[6 * i + 1] = ray.origin.y; rays[6 * i + 2] = ray.origin.z;
+      rays[6 * i + 3] = ray.direction.x; rays[6 * i + 4] = ray.direction.y; rays[6 * i + 5] = ray.direction.z;
+    }
     Hit hit = ray_intersect(sc, &ray);
     if (hits) hits[i] = hit.object_index;
     v3 energy_before = ray.energy;
@@ -362,14 +367,15 @@ static inline float srgb8_decode(uint32_t b) {
 
 /* frag.hlsl:48-66 for one pixel.  D14: SV_POSITION.xy = (x + 0.5, y + 0.5).
  * prev = linear value of the history texel of this same pixel (D13). */
-static inline v3 fs_main(const Scene *sc, uint32_t x, uint32_t y, v3 previous, uint32_t *segments, int32_t *hits) {
+static inline v3 fs_main(const Scene *sc, uint32_t x, uint32_t y, v3 previous, uint32_t *segments, int32_t *hits,
+                         float *rays) {
   float pos_x = (float)x + 0.5f, pos_y = (float)y + 0.5f;
   float pjx = pos_x + sc->frame_data.jitter_x, pjy = pos_y + sc->frame_data.jitter_y;
   float cjx = pjx / (float)sc->config.width, cjy = pjy / (float)sc->config.height;
   Rng rng;
   random_init(&rng, cjx, cjy);
   Ray ray = create_ray(sc, cjx, cjy);
-  v3 colour = trace_ray_with_reflections(sc, &rng, ray, segments, hits);
+  v3 colour = trace_ray_with_reflections(sc, &rng, ray, segments, hits, rays);
   float opacity = 1.0f / (float)(sc->frame_data.progressive_count + 1u);
   float keep = 1.0f - opacity;
   return V(fmaf(colour.x, opacity, previous.x * keep), fmaf(colour.y, opacity, previous.y * keep),
@@ -378,6 +384,12 @@ static inline v3 fs_main(const Scene *sc, uint32_t x, uint32_t y, v3 previous, u
 
 /* ------------------------------------------------------------ entry points */
 #define RTO_EXPORT __attribute__((visibility("default")))
+
+/* Diagnostic: while set, rto_render also stores the ray of every executed iteration — W x H x reflection_limit x
+ * {origin.xyz, direction.xyz}, untouched where an iteration did not run — for tests of the product's culling
+ * structures (every sphere a segment hits must be in the candidate set its ray is given).  NULL switches it off. */
+static float *g_ray_dump = NULL;
+RTO_EXPORT void rto_set_ray_dump(float *rays) { g_ray_dump = rays; }
 
 /* Render rows [y0, y1) of one frame.
  *   objects        object_count x 112 B wire records   config112 / framedata16  wire blobs
@@ -433,7 +445,7 @@ RTO_EXPORT int rto_render(const uint8_t *objects, uint32_t object_count, const u
       uint32_t seg = 0;
       int32_t *hits = out_hits ? out_hits + p * R : NULL;
       if (hits) for (uint32_t i = 0; i < R; ++i) hits[i] = -2;
-      v3 mixed = fs_main(&sc, x, y, previous, &seg, hits);
+      v3 mixed = fs_main(&sc, x, y, previous, &seg, hits, g_ray_dump ? g_ray_dump + p * R * 6 : NULL);
       if (out_rgbf32) { out_rgbf32[3 * p] = mixed.x; out_rgbf32[3 * p + 1] = mixed.y; out_rgbf32[3 * p + 2] = mixed.z; }
       if (out_rgba8) {
         out_rgba8[4 * p] = srgb8_encode(mixed.x);

@@ -17,6 +17,7 @@ RT_ACCUM_SRGB8, RT_ACCUM_FLOAT32 = 0, 1
 RT_OUT_RGBA8, RT_OUT_RGBF32, RT_OUT_SEGMENTS, RT_OUT_HITS = 1, 2, 4, 8
 RT_OPT_VARIANT, RT_OPT_REFILL_MIN, RT_OPT_BLOCKS_PER_CU, RT_OPT_TILE_CHUNK, RT_OPT_FLAGS, RT_OPT_CULL = 0, 1, 2, 3, 4, 5
 RT_OPT_INFLIGHT, RT_OPT_GRID_MIN, RT_OPT_BATCH_INFLIGHT = 6, 7, 8
+RT_OPT_DIRMASK, RT_OPT_DIRMASK_MIN, RT_OPT_DIRMASK_CELLS, RT_OPT_DIRMASK_K = 9, 10, 11, 12
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_NOT_READY",
                 -4: "RT_ERR_DEVICE", -5: "RT_ERR_OUT_OF_MEMORY"}
@@ -35,13 +36,20 @@ class RtStats(C.Structure):
                 ("sphere_count", C.c_uint32), ("plane_count", C.c_uint32), ("last_batch", C.c_uint32),
                 ("last_wave_iterations", C.c_uint64), ("last_cull_mismatches", C.c_uint64),
                 ("last_resolve_ms", C.c_float), ("last_variant", C.c_uint32), ("last_stage", C.c_uint32),
-                ("grid_cells", C.c_uint32), ("grid_items", C.c_uint32)]
+                ("grid_cells", C.c_uint32), ("grid_items", C.c_uint32),
+                ("dirmask_cells", C.c_uint32), ("dirmask_bins", C.c_uint32)]
 
 
 class RtGridInfo(C.Structure):
     _fields_ = [("enabled", C.c_uint32), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32), ("n_cells", C.c_uint32),
                 ("n_items", C.c_uint32), ("gmin", C.c_float * 3), ("gmax", C.c_float * 3), ("cell", C.c_float * 3),
                 ("inv_cell", C.c_float * 3), ("near_min", C.c_float * 3), ("near_max", C.c_float * 3), ("t_margin", C.c_float)]
+
+
+class RtDirMaskInfo(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32), ("k", C.c_uint32),
+                ("bins", C.c_uint32), ("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("cell", C.c_float * 3),
+                ("inv_cell", C.c_float * 3), ("near_min", C.c_float * 3), ("near_max", C.c_float * 3)]
 
 
 class RtDeviceBuffers(C.Structure):
@@ -67,6 +75,9 @@ SIGNATURES = {
     "rt_resize": (_i, [_vp, _u32, _u32]),
     "rt_set_partition": (_i, [_vp, _u32, _u32, _u32]),
     "rt_grid_build_host": (_i, [_vp, _u32, _u32, C.POINTER(RtGridInfo), _vp, _u32, _vp, _u32]),
+    "rt_dirmask_build_host": (_i, [_vp, _u32, _u32, _u32, C.POINTER(RtDirMaskInfo), _vp, _sz]),
+    "rt_dirmask_lookup_host": (_i, [C.POINTER(RtDirMaskInfo), _vp, _vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "rt_comm_available": (_i, [C.c_char_p, _sz]),
     "rt_comm_get_unique_id": (_i, [_vp]),
     "rt_comm_init": (_i, [_vp, _vp, _u32, _u32, _u32]),
     "rt_comm_destroy": (_i, [_vp]),
@@ -106,6 +117,24 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the sources librt355.so is built from (csrc/*.hip, *.h, *.cpp, Makefile; include/*.h), in name
+    order.  Profiles record it (tools/pmc_summary.py) and bench.py only quotes a profile's counters when the tree it
+    runs from still has the sources the profile was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_HERE)
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "csrc", "Makefile")] +
+                   glob.glob(os.path.join(root, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def _preload_torch_hip_runtime():

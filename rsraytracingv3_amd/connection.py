@@ -94,6 +94,13 @@ class Device:
 
     # -- multi-GPU frame (one process per GPU; the gather runs inside the library over RCCL) ---------------
     @staticmethod
+    def comm_available():
+        """rt_comm_available: (True, path of the RCCL bound) or (False, why not).  Not a collective; needs no GPU."""
+        buf = C.create_string_buffer(1024)
+        rc = N.load().rt_comm_available(buf, len(buf))
+        return rc == N.RT_OK, buf.value.decode("utf-8", "replace")
+
+    @staticmethod
     def comm_unique_id() -> bytes:
         """Rank 0: the 128 opaque bytes every rank passes to ``comm_init`` (hand them over by any channel)."""
         lib = N.load()

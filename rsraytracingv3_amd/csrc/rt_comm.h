@@ -24,7 +24,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional: rt_comm_abort falls back to leaking the communicator
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // required: the only way out of an exchange that never completes
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -66,7 +66,8 @@ inline const RcclApi &rccl_api(std::string *why) {
     for (int i = 0; i < n && !api.handle; ++i) {
       void *h = dlopen(candidates[i].c_str(), RTLD_NOW | RTLD_LOCAL);
       if (!h) {
-        error += candidates[i] + ": " + (dlerror() ? dlerror() : "dlopen failed") + "; ";
+        const char *e = dlerror();  // one call: dlerror() clears the message it returns
+        error += candidates[i] + ": " + (e ? e : "dlopen failed") + "; ";
         continue;
       }
       RcclApi a;
@@ -79,7 +80,7 @@ inline const RcclApi &rccl_api(std::string *why) {
       a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
       a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
       a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-      if (a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.Send && a.Recv && a.GroupStart && a.GroupEnd && a.GetErrorString) {
+      if (a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.CommAbort && a.Send && a.Recv && a.GroupStart && a.GroupEnd && a.GetErrorString) {
         a.handle = h;
         a.path = candidates[i];
         api = a;

@@ -12,6 +12,7 @@
 #include <cstdint>
 
 #include "rt_math.h"
+#include "rt_dirmask.h"
 
 namespace rt355 {
 
@@ -55,6 +56,7 @@ struct GridParams {
 struct DeviceScene {
   const float4 *image;
   GridParams grid;
+  DirMaskParams dm;        // candidate-sphere masks for secondary rays (rt_dirmask.h); scenes of up to 64 spheres
   uint32_t n_sph, n_pl, n_obj;
   uint32_t n_sph_pad;      // records in sph[]: n_sph rounded up to kSphBatch, plus one batch of read-ahead
   uint32_t image_records;  // float4 records in the whole image
@@ -190,6 +192,8 @@ struct AssembleParams {
 };
 int launch_assemble(const AssembleParams &ap, hipStream_t stream);
 int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned long long *masks, hipStream_t stream);
+// fills dm.table ([cells][bins] 64-bit sets) from the n registered spheres reg[] = {c, r_reg} (device memory)
+int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n, unsigned long long *table, hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);
 int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream);
 

@@ -238,6 +238,7 @@ struct SceneView {
   uint32_t n_sph_pad, n_pl;
   const uint32_t *grid_cells;  // cell_start[n_cells + 1], or null
   const uint16_t *grid_items;
+  const DirMaskParams *dm;     // candidate-sphere masks for secondary rays (rt_dirmask.h); enabled == 0: none
 };
 // `sph_base`: record 0 of the sphere array; `rest_base`: record 0 of an image that holds everything else
 // (the two are the same pointer when the whole image was staged).
@@ -255,6 +256,7 @@ __device__ __forceinline__ SceneView make_view(const DeviceScene &sc, const floa
   v.n_pl = sc.n_pl;
   v.grid_cells = nullptr;
   v.grid_items = nullptr;
+  v.dm = &sc.dm;
   return v;
 }
 
@@ -429,6 +431,68 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
       }
     }
   }
+  return SphereHit{best_key, slot};
+}
+
+// ---- direction masks (rt_dirmask.h): secondary rays of scenes with up to 64 spheres --------------------------------
+// The candidate set of this lane's ray as two 32-bit words (0 for lanes without a ray, and for rays that miss the box of
+// the registered balls).  Returns false — wave-uniform — when some live lane's ray is not served by the table (origin
+// outside the near box, direction not a unit vector, NaN): the wave then scans linearly as before.
+__device__ __forceinline__ bool dirmask_lookup(const DirMaskParams &dm, f3 o, f3 d, bool alive, uint32_t &lo, uint32_t &hi) {
+  const bool served = (fabsf(dot3(d, d) - 1.0f) <= 4e-6f) & (o.x >= dm.near_min[0]) & (o.x <= dm.near_max[0]) &
+                      (o.y >= dm.near_min[1]) & (o.y <= dm.near_max[1]) & (o.z >= dm.near_min[2]) & (o.z <= dm.near_max[2]);
+  if (__builtin_amdgcn_ballot_w64(alive & !served) != 0ull) return false;
+  f3 p = o;
+  bool reaches = true;
+  const bool outside = !((o.x >= dm.bmin[0]) & (o.x <= dm.bmax[0]) & (o.y >= dm.bmin[1]) & (o.y <= dm.bmax[1]) &
+                         (o.z >= dm.bmin[2]) & (o.z <= dm.bmax[2]));
+  if (__builtin_amdgcn_ballot_w64(alive & outside) != 0ull) {
+    // rays that start outside the box continue from the point where they enter it; a ray that misses it meets no sphere
+    const float big = 1e30f;
+    const float ivx = fabsf(d.x) > 1e-30f ? __builtin_amdgcn_rcpf(d.x) : (d.x < 0.0f ? -big : big);
+    const float ivy = fabsf(d.y) > 1e-30f ? __builtin_amdgcn_rcpf(d.y) : (d.y < 0.0f ? -big : big);
+    const float ivz = fabsf(d.z) > 1e-30f ? __builtin_amdgcn_rcpf(d.z) : (d.z < 0.0f ? -big : big);
+    const float ax = (dm.bmin[0] - o.x) * ivx, bx = (dm.bmax[0] - o.x) * ivx;
+    const float ay = (dm.bmin[1] - o.y) * ivy, by = (dm.bmax[1] - o.y) * ivy;
+    const float az = (dm.bmin[2] - o.z) * ivz, bz = (dm.bmax[2] - o.z) * ivz;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    reaches = !outside | (t_in <= t_out);
+    p = outside ? fma3(d, t_in, o) : o;
+  }
+  const uint32_t cell = dirmask_cell(dm, p);
+  const float inv_major = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
+  const uint32_t bin = dirmask_bin(d, inv_major, dm.k, dm.half_k);
+  unsigned long long m = 0ull;
+  if (alive & reaches) m = dm.table[static_cast<size_t>(cell) * dm.bins + bin];
+  lo = static_cast<uint32_t>(m);
+  hi = static_cast<uint32_t>(m >> 32);
+  return true;
+}
+
+// The sphere part of ray.hlsl:97-107 over this lane's candidate set, lanes diverge: ascending slots, the arithmetic of
+// the linear scan, strict '<' — the lexicographic (key, slot) minimum over the set, which is the linear scan's result
+// because the set holds every sphere the scan could accept (rt_dirmask.h).
+__device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restrict__ sph, f3 o, f3 d, uint32_t lo, uint32_t hi) {
+  uint32_t best_key = kNoHitKey;
+  int slot = -1;
+#define RT_MASK_WORD(word_, base)                                                                  \
+  while (word_ != 0u) {                                                                            \
+    const uint32_t i = (base) + static_cast<uint32_t>(__builtin_ctz(word_));                       \
+    word_ &= word_ - 1u;                                                                           \
+    const float4 g = sph[i];                                                                       \
+    const float nx = o.x - g.x, ny = o.y - g.y, nz = o.z - g.z;                                    \
+    const float dn = fmaf(d.z, nz, fmaf(d.y, ny, d.x * nx));                                       \
+    const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));                    \
+    if (fminf(q, -dn) >= 0.0f) {                                                                   \
+      const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;                      \
+      slot = (key < best_key) ? static_cast<int>(i) : slot;                                        \
+      best_key = min(best_key, key);                                                               \
+    }                                                                                              \
+  }
+  RT_MASK_WORD(lo, 0u)
+  RT_MASK_WORD(hi, 32u)
+#undef RT_MASK_WORD
   return SphereHit{best_key, slot};
 }
 
@@ -682,6 +746,17 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
     RT_REQUEST_X2
     if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     RT_PH_MARK(3)
+  } else if (uint32_t lo = 0u, hi = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, lo, hi)) {
+    // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
+    const SphereHit sh = scan_spheres_masked(sv.sph, s.o, s.d, lo, hi);
+    if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
+      const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
+      if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
+    }
+    RT_PH_MARK(1)
+    RT_REQUEST_X2
+    if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+    RT_PH_MARK(3)
   } else if (n_live <= 32u) {
     const SphereHit sh = scan_spheres_coop(sv.sph, sv.n_sph_pad, s.o, s.d, alive, live, n_live);
     RT_PH_MARK(2)
@@ -734,6 +809,16 @@ __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FramePa
       h = finish_hit(sv, sh, s.o, s.d);
     }
     RT_PH_MARK(0)
+  } else if (uint32_t lo = 0u, hi = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, lo, hi)) {
+    // secondary rays of a small scene: every lane tests its own candidate set
+    const SphereHit sh = scan_spheres_masked(sv.sph, s.o, s.d, lo, hi);
+    if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
+      const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
+      if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
+    }
+    RT_PH_MARK(1)
+    if (alive) h = finish_hit(sv, sh, s.o, s.d);
+    RT_PH_MARK(3)
   } else if (n_live <= 32u) {
     const SphereHit sh = scan_spheres_coop(sv.sph, sv.n_sph_pad, s.o, s.d, alive, live, n_live);
     RT_PH_MARK(2)
@@ -1482,6 +1567,17 @@ __global__ void __launch_bounds__(256) cull_slabs_kernel(DeviceScene sc, FramePa
   }
 }
 
+// Fills the direction-mask table (rt_dirmask.h): one thread per (cell, bin) entry.
+__global__ void __launch_bounds__(256) dirmask_build_kernel(DirMaskParams dm, const float4 *reg, uint32_t n, unsigned long long *table,
+                                                            unsigned long long entries) {
+  __shared__ float4 s_reg[kDirMaskMaxSpheres];
+  if (threadIdx.x < n) s_reg[threadIdx.x] = reg[threadIdx.x];
+  __syncthreads();
+  const unsigned long long e = static_cast<unsigned long long>(blockIdx.x) * 256ull + threadIdx.x;
+  if (e >= entries) return;
+  table[e] = dirmask_entry(dm, static_cast<uint32_t>(e / dm.bins), static_cast<uint32_t>(e % dm.bins), s_reg, n);
+}
+
 // Second pass of a batch launch (rt_render_frames): folds the batch's float samples into the history
 // in frame order, i.e. replays frag.hlsl:60-65 + the Rgba8UnormSrgb store once per frame exactly as
 // path_end would have done in `batch` separate launches (same expression, same quantisation of every
@@ -1744,6 +1840,14 @@ int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned lon
   if (tiles_x * tiles_y == 0 || fp.mask_words == 0) return 0;
   hipLaunchKernelGGL(cull_slabs_kernel, dim3((tiles_x + tiles_y + 3) / 4), dim3(256), 0, stream, sc, fp, masks, tiles_x,
                      tiles_y);
+  return static_cast<int>(hipGetLastError());
+}
+
+int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n, unsigned long long *table, hipStream_t stream) {
+  const unsigned long long entries = static_cast<unsigned long long>(dm.nx) * dm.ny * dm.nz * dm.bins;
+  if (entries == 0 || n == 0 || n > kDirMaskMaxSpheres) return static_cast<int>(hipErrorInvalidValue);
+  hipLaunchKernelGGL(dirmask_build_kernel, dim3(static_cast<uint32_t>((entries + 255ull) / 256ull)), dim3(256), 0, stream, dm, reg, n,
+                     table, entries);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -10,9 +10,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rt355.h"
@@ -118,6 +120,15 @@ struct rt_context {
   int batch_inflight = 1;  // RT_OPT_BATCH_INFLIGHT
   uint64_t prep_generation = 0;                 // bumped whenever prep_done is re-recorded
   uint64_t prep_seen[kMaxInflight] = {};        // generation each render stream has already waited for
+  // direction masks (rt_dirmask.h): table of candidate-sphere sets for the secondary rays of scenes with up to 64 spheres
+  int dirmask_on = 1;            // RT_OPT_DIRMASK
+  int dirmask_min_spheres = 12;  // RT_OPT_DIRMASK_MIN: smaller scenes scan linearly (the lookup costs more than their scan)
+  int dirmask_cells = 4096;      // RT_OPT_DIRMASK_CELLS: cells aimed at
+  int dirmask_k = 8;             // RT_OPT_DIRMASK_K: bins per cube-map face edge
+  unsigned long long *d_dirmask = nullptr;
+  size_t dirmask_cap = 0;        // in entries
+  float4 *d_dirmask_reg = nullptr;
+  std::vector<float4> dirmask_built_for;  // sphere records (+ one record of options) the table on the device was built from
   int grid_min_spheres = 88;   // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid (A/B on one
                                // device, tools/grid_threshold_sweep.sh, Grays/s linear / grid: 64 spheres 40.2 / 32.4, 80: 47.5 /
                                // 47.3, 88: 45.2 / 46.3, 96: 41.9 / 45.5, 128: 33.7 / 40.6)
@@ -126,6 +137,7 @@ struct rt_context {
   bool resolve_pending[kMaxInflight] = {};  // pipe_samples[i] has been written; its resolve is ev_resolved[resolve_slot[i]]
   uint32_t resolve_slot[kMaxInflight] = {};
   bool prep_pending = false;                // work the renders depend on was queued on the main stream (prep_done)
+  bool prep_pending_dirmask = false;        // the direction-mask build was queued on the main stream since the last launch
   float *d_pipe_samples[kMaxInflight] = {};
   size_t pipe_cap[kMaxInflight] = {};  // in floats
   // path queues of the streamed shape (variant 4): one per pipelined lane, the last one for multi-frame launches
@@ -306,9 +318,53 @@ int read_back(rt_context *ctx, const T *src, void *dst, size_t bytes, size_t ele
   return RT_OK;
 }
 
+// The direction-mask table of the current spheres (rt_dirmask.h), rebuilt on the device only when the sphere records
+// or the table's options changed (a moving camera re-sends the same objects every frame, connection.rs:373-385).
+// Leaves ctx->scene.dm disabled when the scene is not served.
+constexpr size_t kDirMaskMaxEntries = 8u << 20;  // 64 MB
+int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
+  float4 reg[kDirMaskMaxSpheres];
+  uint32_t target = static_cast<uint32_t>(ctx->dirmask_cells);
+  DirMaskParams dm = dirmask_plan(sph, n, target, static_cast<uint32_t>(ctx->dirmask_k), reg);
+  while (dm.enabled && static_cast<size_t>(dm.nx) * dm.ny * dm.nz * dm.bins > kDirMaskMaxEntries && target > 1u) {
+    target /= 2u;
+    dm = dirmask_plan(sph, n, target, static_cast<uint32_t>(ctx->dirmask_k), reg);
+  }
+  if (!dm.enabled) return RT_OK;
+  const size_t entries = static_cast<size_t>(dm.nx) * dm.ny * dm.nz * dm.bins;
+  if (entries > kDirMaskMaxEntries) return RT_OK;
+  std::vector<float4> key(sph, sph + n);
+  key.push_back(make_float4(static_cast<float>(dm.nx), static_cast<float>(dm.ny), static_cast<float>(dm.nz), static_cast<float>(dm.k)));
+  const bool same = ctx->d_dirmask && key.size() == ctx->dirmask_built_for.size() &&
+                    std::memcmp(key.data(), ctx->dirmask_built_for.data(), key.size() * sizeof(float4)) == 0;
+  if (!same) {
+    ctx->dirmask_built_for.clear();
+    if (ctx->dirmask_cap < entries) {
+      (void)hipFree(ctx->d_dirmask);
+      ctx->d_dirmask = nullptr;
+      ctx->dirmask_cap = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_dirmask, entries * sizeof(unsigned long long)));
+      ctx->dirmask_cap = entries;
+    }
+    if (!ctx->d_dirmask_reg) RT_HIP(ctx, hipMalloc(&ctx->d_dirmask_reg, kDirMaskMaxSpheres * sizeof(float4)));
+    RT_HIP(ctx, hipMemcpy(ctx->d_dirmask_reg, reg, n * sizeof(float4), hipMemcpyHostToDevice));
+    if (launch_dirmask_build(dm, ctx->d_dirmask_reg, n, ctx->d_dirmask, ctx->stream) != 0)
+      return fail(ctx, RT_ERR_DEVICE, "direction-mask build launch failed");
+    ctx->dirmask_built_for = key;
+    ctx->prep_pending_dirmask = true;
+  }
+  dm.table = ctx->d_dirmask;
+  ctx->scene.dm = dm;
+  return RT_OK;
+}
+
+constexpr int kCommPatienceMs = 20000;  // how long leaving a communicator waits for the exchange in flight before it aborts it
+
 }  // namespace
 
 extern "C" {
+
+static void release_comm(rt_context *ctx, int patience_ms);
 
 uint32_t rt_abi_version(void) { return RT355_ABI_VERSION; }
 
@@ -361,15 +417,10 @@ int rt_create(int device_id, rt_context **out_ctx) {
 int rt_destroy(rt_context *ctx) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   (void)hipSetDevice(ctx->device);
+  release_comm(ctx, kCommPatienceMs);       // before any synchronisation: a stuck exchange is aborted, not waited for
   (void)hipStreamSynchronize(ctx->stream);  // also when the caller bound the null stream (rt_set_stream)
   if (ctx->upload_stream) (void)hipStreamSynchronize(ctx->upload_stream);
   if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
-  if (ctx->comm) {
-    std::string why;
-    const RcclApi &api = rccl_api(&why);
-    if (api.ok()) (void)api.CommDestroy(ctx->comm);
-    ctx->comm = nullptr;
-  }
   for (int i = 0; i < 2; ++i) {
     if (ctx->frame_ready[i]) (void)hipEventDestroy(ctx->frame_ready[i]);
     if (ctx->gather_done[i]) (void)hipEventDestroy(ctx->gather_done[i]);
@@ -383,6 +434,8 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_counters);
   (void)hipFree(ctx->d_tile_counters);
   (void)hipFree(ctx->d_masks);
+  (void)hipFree(ctx->d_dirmask);
+  (void)hipFree(ctx->d_dirmask_reg);
   (void)hipFree(ctx->d_samples);
   (void)hipFree(ctx->d_queue[rt_context::kMaxInflight]);
   (void)hipFree(ctx->d_kept);
@@ -612,6 +665,12 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   ctx->scene.n_obj = object_count;
   ctx->scene.image_records = static_cast<uint32_t>(image_records);
   ctx->scene.grid = grid.params;
+  ctx->scene.dm = DirMaskParams{};
+  if (ctx->dirmask_on && !grid.params.enabled && n_sph_live >= static_cast<size_t>(ctx->dirmask_min_spheres) &&
+      n_sph_live <= kDirMaskMaxSpheres) {
+    const int drc = build_dirmask(ctx, sph.data(), static_cast<uint32_t>(n_sph_live));
+    if (drc != RT_OK) return drc;
+  }
   ctx->have_scene = true;
   ctx->masks_dirty = true;
   ctx->stats.object_count = object_count;
@@ -678,6 +737,102 @@ int rt_grid_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t 
   }
 }
 
+// Host-side twin of the direction-mask table (rt_dirmask.h), for inspection and for testing its sets without a GPU.
+static DirMaskParams dirmask_from_info(const rt_dirmask_info *info) {
+  DirMaskParams dm{};
+  dm.enabled = info->enabled;
+  dm.nx = info->nx;
+  dm.ny = info->ny;
+  dm.nz = info->nz;
+  dm.k = info->k;
+  dm.bins = info->bins;
+  dm.half_k = 0.5f * static_cast<float>(info->k);
+  for (int a = 0; a < 3; ++a) {
+    dm.bmin[a] = info->bmin[a];
+    dm.bmax[a] = info->bmax[a];
+    dm.cell[a] = info->cell[a];
+    dm.inv_cell[a] = info->inv_cell[a];
+    dm.near_min[a] = info->near_min[a];
+    dm.near_max[a] = info->near_max[a];
+  }
+  return dm;
+}
+
+int rt_dirmask_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t target_cells, uint32_t k, rt_dirmask_info *info,
+                          uint64_t *table, size_t table_cap) {
+  if (!info || (!spheres_xyzr2 && n_spheres)) return RT_ERR_INVALID_ARGUMENT;
+  std::memset(info, 0, sizeof *info);
+  if (n_spheres == 0 || n_spheres > kDirMaskMaxSpheres) return RT_OK;  // not served: info->enabled stays 0
+  float4 sph[kDirMaskMaxSpheres], reg[kDirMaskMaxSpheres];
+  for (uint32_t i = 0; i < n_spheres; ++i)
+    sph[i] = make_float4(spheres_xyzr2[4 * i], spheres_xyzr2[4 * i + 1], spheres_xyzr2[4 * i + 2], spheres_xyzr2[4 * i + 3]);
+  const DirMaskParams dm = dirmask_plan(sph, n_spheres, target_cells, k, reg);
+  if (!dm.enabled) return RT_OK;
+  info->enabled = 1;
+  info->nx = dm.nx;
+  info->ny = dm.ny;
+  info->nz = dm.nz;
+  info->k = dm.k;
+  info->bins = dm.bins;
+  for (int a = 0; a < 3; ++a) {
+    info->bmin[a] = dm.bmin[a];
+    info->bmax[a] = dm.bmax[a];
+    info->cell[a] = dm.cell[a];
+    info->inv_cell[a] = dm.inv_cell[a];
+    info->near_min[a] = dm.near_min[a];
+    info->near_max[a] = dm.near_max[a];
+  }
+  const size_t entries = static_cast<size_t>(dm.nx) * dm.ny * dm.nz * dm.bins;
+  if (table && table_cap >= entries)
+    for (size_t e = 0; e < entries; ++e)
+      table[e] = dirmask_entry(dm, static_cast<uint32_t>(e / dm.bins), static_cast<uint32_t>(e % dm.bins), reg, n_spheres);
+  return RT_OK;
+}
+
+int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, const float *origin3, const float *direction3,
+                           uint64_t *mask, int *served) {
+  if (!info || !table || !origin3 || !direction3 || !mask || !served || !info->enabled) return RT_ERR_INVALID_ARGUMENT;
+  const DirMaskParams dm = dirmask_from_info(info);
+  const f3 o = mk3(origin3[0], origin3[1], origin3[2]), d = mk3(direction3[0], direction3[1], direction3[2]);
+  *mask = 0;
+  *served = 0;
+  // the lane's arithmetic (dirmask_lookup in rt_kernels.hip), with an IEEE reciprocal where the device uses v_rcp_f32
+  const bool ok = (fabsf(dot3(d, d) - 1.0f) <= 4e-6f) && (o.x >= dm.near_min[0]) && (o.x <= dm.near_max[0]) && (o.y >= dm.near_min[1]) &&
+                  (o.y <= dm.near_max[1]) && (o.z >= dm.near_min[2]) && (o.z <= dm.near_max[2]);
+  if (!ok) return RT_OK;
+  *served = 1;
+  f3 p = o;
+  const bool outside = !((o.x >= dm.bmin[0]) && (o.x <= dm.bmax[0]) && (o.y >= dm.bmin[1]) && (o.y <= dm.bmax[1]) && (o.z >= dm.bmin[2]) &&
+                         (o.z <= dm.bmax[2]));
+  if (outside) {
+    const float big = 1e30f;
+    const float ivx = fabsf(d.x) > 1e-30f ? 1.0f / d.x : (d.x < 0.0f ? -big : big);
+    const float ivy = fabsf(d.y) > 1e-30f ? 1.0f / d.y : (d.y < 0.0f ? -big : big);
+    const float ivz = fabsf(d.z) > 1e-30f ? 1.0f / d.z : (d.z < 0.0f ? -big : big);
+    const float ax = (dm.bmin[0] - o.x) * ivx, bx = (dm.bmax[0] - o.x) * ivx;
+    const float ay = (dm.bmin[1] - o.y) * ivy, by = (dm.bmax[1] - o.y) * ivy;
+    const float az = (dm.bmin[2] - o.z) * ivz, bz = (dm.bmax[2] - o.z) * ivz;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    if (!(t_in <= t_out)) return RT_OK;  // misses the box: the empty set
+    p = fma3(d, t_in, o);
+  }
+  const uint32_t cell = dirmask_cell(dm, p);
+  const float inv_major = 1.0f / fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+  *mask = table[static_cast<size_t>(cell) * dm.bins + dirmask_bin(d, inv_major, dm.k, dm.half_k)];
+  return RT_OK;
+}
+
+int rt_comm_available(char *why_buf, size_t why_cap) {
+  std::string why;
+  const RcclApi &api = rccl_api(&why);
+  if (why_buf && why_cap) {
+    const std::string &text = api.ok() ? api.path : why;
+    std::snprintf(why_buf, why_cap, "%s", text.c_str());
+  }
+  return api.ok() ? RT_OK : RT_ERR_NOT_READY;
+}
+
 int rt_comm_get_unique_id(void *id128) {
   if (!id128) return RT_ERR_INVALID_ARGUMENT;
   std::string why;
@@ -727,16 +882,38 @@ int rt_comm_init(rt_context *ctx, const void *id128, uint32_t rank, uint32_t wor
   return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
 }
 
+// Leaving a communicator: waits for the exchange in flight — but only for `patience_ms`; an exchange that has not
+// completed by then (a peer that never posted its side) is given up with ncclCommAbort, after which the RCCL kernel on
+// the communication stream ends and the streams can be synchronised.  Never hangs.
+static void release_comm(rt_context *ctx, int patience_ms) {
+  if (!ctx->comm) return;
+  std::string why;
+  const RcclApi &api = rccl_api(&why);
+  bool done = false;
+  for (int waited = 0; !done; waited += 2) {
+    hipError_t e = hipStreamQuery(ctx->stream);
+    if (e == hipSuccess && ctx->comm_stream) e = hipStreamQuery(ctx->comm_stream);
+    (void)hipGetLastError();
+    done = e != hipErrorNotReady;  // finished, or broken: either way nothing to wait for
+    if (done || waited >= patience_ms) break;
+    std::this_thread::sleep_for(std::chrono::milliseconds(2));
+  }
+  if (api.ok()) {
+    if (done) (void)api.CommDestroy(ctx->comm);
+    else (void)api.CommAbort(ctx->comm);
+  }
+  ctx->comm = nullptr;
+  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipGetLastError();
+  ctx->gather_pending[0] = ctx->gather_pending[1] = false;
+}
+
 int rt_comm_destroy(rt_context *ctx) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!ctx->comm) return RT_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
-  std::string why;
-  const RcclApi &api = rccl_api(&why);
-  if (api.ok()) (void)api.CommDestroy(ctx->comm);
-  ctx->comm = nullptr;
+  release_comm(ctx, kCommPatienceMs);
   ctx->comm_world = 0;
   ctx->comm_rank = 0;
   ctx->rank = 0;
@@ -759,17 +936,11 @@ int rt_comm_abort(rt_context *ctx) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!ctx->comm) return RT_OK;
   (void)hipSetDevice(ctx->device);
-  std::string why;
-  const RcclApi &api = rccl_api(&why);
-  // no synchronisation first: the point is to get rid of an exchange that does not finish
-  if (api.ok() && api.CommAbort) (void)api.CommAbort(ctx->comm);
-  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
-  (void)hipStreamSynchronize(ctx->stream);
-  (void)hipGetLastError();
-  ctx->comm = nullptr;
+  // no waiting first: the point is to get rid of an exchange that does not finish (ncclCommAbort is part of the
+  // required symbol set of rt_comm.h, so the synchronisation inside release_comm cannot meet a live RCCL kernel)
+  release_comm(ctx, 0);
   ctx->comm_world = 0;
   ctx->comm_rank = 0;
-  ctx->gather_pending[0] = ctx->gather_pending[1] = false;
   ctx->rank = 0;
   ctx->world = 1;
   return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
@@ -866,6 +1037,20 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       if (value < 1 || value > rt_context::kMaxInflight)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_INFLIGHT takes 1..%d", rt_context::kMaxInflight);
       ctx->inflight = value;  // a frame already in flight keeps its lane: lanes are only re-used after their resolve
+      return RT_OK;
+    case RT_OPT_DIRMASK:
+      ctx->dirmask_on = value != 0;
+      return RT_OK;
+    case RT_OPT_DIRMASK_MIN:
+      ctx->dirmask_min_spheres = value < 1 ? 1 : value;
+      return RT_OK;
+    case RT_OPT_DIRMASK_CELLS:
+      if (value < 1 || value > 262144) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_DIRMASK_CELLS takes 1..262144");
+      ctx->dirmask_cells = value;
+      return RT_OK;
+    case RT_OPT_DIRMASK_K:
+      if (value < 1 || value > static_cast<int>(kDirMaskMaxK)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_DIRMASK_K takes 1..%u", kDirMaskMaxK);
+      ctx->dirmask_k = value;
       return RT_OK;
     case RT_OPT_BATCH_INFLIGHT:
       if (value < 1 || value > rt_context::kMaxInflight)
@@ -1123,6 +1308,10 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
                                (rt_context::kRing / 2) * rt_context::kCounterWords * sizeof(unsigned long long), ctx->stream));
     prep_queued = true;
   }
+  if (ctx->prep_pending_dirmask) {  // rt_set_scene queued the direction-mask build on the main stream
+    prep_queued = true;
+    ctx->prep_pending_dirmask = false;
+  }
   if (prep_queued) {  // render streams must not start before the masks / re-armed counters are there
     RT_HIP(ctx, hipEventRecord(ctx->prep_done, ctx->stream));
     ctx->prep_pending = true;
@@ -1203,6 +1392,8 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   ctx->stats.last_stage = static_cast<uint32_t>(stage_used);
   ctx->stats.grid_cells = ctx->scene.grid.enabled ? ctx->scene.grid.n_cells : 0u;
   ctx->stats.grid_items = ctx->scene.grid.enabled ? ctx->scene.grid.n_items : 0u;
+  ctx->stats.dirmask_cells = ctx->scene.dm.enabled ? ctx->scene.dm.nx * ctx->scene.dm.ny * ctx->scene.dm.nz : 0u;
+  ctx->stats.dirmask_bins = ctx->scene.dm.enabled ? ctx->scene.dm.bins : 0u;
   if (fp.hits) {
     ctx->hits_valid = true;
     ctx->hits_rendered_limit = fp.reflection_limit;
@@ -1315,8 +1506,12 @@ int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes) {
   if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_write_history_rgba8: %zu bytes given, %zu expected", bytes, need);
   RT_HIP(ctx, hipSetDevice(ctx->device));
   uint32_t *history = ctx->ext_rgba8 ? (ctx->ext_hist_rgba8 ? ctx->ext_hist_rgba8 : ctx->ext_rgba8) : ctx->d_rgba8;
-  if (ctx->comm && !ctx->ext_rgba8)  // the next launch reads the buffer it does not write
-    history = (ctx->comm_launches & 1u) ? ctx->d_rgba8 : ctx->d_rgba8_alt;
+  if (ctx->comm && !ctx->ext_rgba8) {  // the next launch reads the buffer it does not write ...
+    const int idx = (ctx->comm_launches & 1u) ? 0 : 1;
+    history = idx ? ctx->d_rgba8_alt : ctx->d_rgba8;
+    // ... which is the one the previous launch wrote and whose gather may still be sending from it
+    if (ctx->gather_pending[idx]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gather_done[idx], 0));
+  }
   RT_HIP(ctx, hipMemcpyAsync(history, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return RT_OK;
@@ -1324,8 +1519,8 @@ int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes) {
 
 int rt_get_device_buffers(rt_context *ctx, rt_device_buffers *out) {
   if (!ctx || !out) return RT_ERR_INVALID_ARGUMENT;
-  out->rgba8 = ctx->d_rgba8;
-  out->rgbf32 = ctx->d_rgbf32;
+  out->rgba8 = const_cast<uint32_t *>(current_texels(ctx));  // comm mode: the target of the last launch
+  out->rgbf32 = ctx->ext_rgba8 ? ctx->ext_rgbf32 : ctx->d_rgbf32;
   out->segments = ctx->d_segments;
   out->hits = ctx->d_hits;
   out->stream = ctx->stream;

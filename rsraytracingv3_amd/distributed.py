@@ -158,22 +158,88 @@ class TorchTileRenderer:
         return frame
 
 
+class CommUnavailable(RuntimeError):
+    """The RCCL communicator of ``TileParallelRenderer`` could not be formed.  Raised on EVERY rank of the group (the
+    ranks agree before any of them raises), so the caller can switch all of them to another transport.  ``fatal``:
+    this rank is still inside ``ncclCommInitRank`` on a helper thread (a peer never arrived) — its context must not
+    be used again; exit the process."""
+
+    def __init__(self, text: str, fatal: bool = False):
+        super().__init__(text)
+        self.fatal = fatal
+
+
+def _all_ranks(ok: bool, group=None) -> bool:
+    """Collective on the process group: True only when every rank says True."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.tensor([1.0 if ok else 0.0], device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item() > 0.5)
+
+
 class TileParallelRenderer:
     """One process per GPU, the image gather inside the C-ABI library (``rt_comm_init``, ``include/rt355.h``).
 
     Every rank issues the same ``render`` calls; after each launch the rank's strips travel to rank 0 over RCCL
     beside the next launch's rendering.  ``finish`` waits and returns the assembled (height, width, 4) uint8 frame
-    on rank 0.  The process group (any backend) is used once, to hand rank 0's communicator id to the others."""
+    on rank 0.  The process group (any backend) only carries the hand-shake: whether every rank can bind RCCL, rank
+    0's communicator id, and whether every rank joined.
 
-    def __init__(self, rt_device, width: int, height: int, strip_rows: int = 8, group=None):
+    Forming the communicator cannot leave the ranks in different states: (1) every rank probes RCCL without a
+    collective (``rt_comm_available``) and the ranks agree before anyone enters ``ncclCommInitRank``; (2) rank 0
+    always broadcasts an (ok, id) pair, also when it could not make an id; (3) ``rt_comm_init`` runs on a helper
+    thread under ``init_timeout_s`` and the ranks agree on its outcome.  Any failure raises ``CommUnavailable`` on
+    every rank."""
+
+    def __init__(self, rt_device, width: int, height: int, strip_rows: int = 8, group=None, init_timeout_s: float = 120.0):
+        import threading
         self.rt = rt_device
         self.width, self.height = width, height
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        ident = [type(rt_device).comm_unique_id() if self.rank == 0 else None]
+        cls = type(rt_device)
+        # (1) can every rank bind RCCL at all?
+        try:
+            usable, text = cls.comm_available()
+        except Exception as exc:  # e.g. a library without the entry point
+            usable, text = False, str(exc)
+        if not _all_ranks(usable, group):
+            raise CommUnavailable("no RCCL on rank %d: %s" % (self.rank, text) if not usable else "another rank cannot bind RCCL")
+        # (2) rank 0's id, or why there is none — a broadcast either way
+        ident = [None]
+        if self.rank == 0:
+            try:
+                ident = [(True, cls.comm_unique_id())]
+            except Exception as exc:
+                ident = [(False, str(exc))]
         if self.world > 1:
             dist.broadcast_object_list(ident, src=0, group=group)
-        rt_device.comm_init(ident[0], self.rank, self.world, strip_rows)
+        if not ident[0][0]:
+            raise CommUnavailable("rank 0 could not create the communicator id: %s" % ident[0][1])
+        # (3) the collective itself, bounded
+        outcome = {}
+
+        def join():
+            try:
+                rt_device.comm_init(ident[0][1], self.rank, self.world, strip_rows)
+                outcome["ok"] = True
+            except Exception as exc:
+                outcome["error"] = str(exc)
+
+        worker = threading.Thread(target=join, name="rt_comm_init", daemon=True)
+        worker.start()
+        worker.join(init_timeout_s)
+        stuck = worker.is_alive()
+        joined = bool(outcome.get("ok")) and not stuck
+        if not _all_ranks(joined, group):
+            if joined:
+                rt_device.comm_abort()  # the peers are not there: never wait for them
+            why = ("rt_comm_init still running after %.0f s on rank %d" % (init_timeout_s, self.rank)) if stuck else \
+                  (("rt_comm_init failed on rank %d: %s" % (self.rank, outcome.get("error"))) if not joined
+                   else "rt_comm_init failed on another rank")
+            raise CommUnavailable(why, fatal=stuck)
         self._render = rt_device._lib.rt_render
         self._render_frames = rt_device._lib.rt_render_frames
 

@@ -27,6 +27,10 @@ local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 
 if world > 1:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
+usable, rccl_text = Device.comm_available()  # not a collective: every rank asks before anyone joins
+if not usable:
+    print("rank %d: no RCCL (%s)" % (rank, rccl_text), flush=True)
+    sys.exit(2)
 ident = [Device.comm_unique_id() if rank == 0 else None]
 if world > 1:
     dist.broadcast_object_list(ident, src=0)
@@ -70,6 +74,44 @@ for accum in (N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32):
     if rank == 0:
         frame = dev.read_frame_rgba8(W, H)
         ok = ok and np.array_equal(frame, ref.rgba8)
+# With a communicator the two targets alternate: rt_get_device_buffers must name the one the last launch wrote, and
+# rt_write_history_rgba8 the one the next launch reads (waiting for the gather that may still send from it).
+import ctypes as C  # noqa: E402
+hip = C.CDLL(None)  # the HIP runtime the library runs on is already mapped
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+dev.set_accum_mode(N.RT_ACCUM_SRGB8)
+target = RenderTarget.new(dev, (W, H))
+conn.last_size = (0, 0)
+conn.update_buffers((W, H), scene, (0.0, 0.0))
+rows = dev.stats().local_rows
+seen = set()
+for k in range(3):
+    conn.frame_data.jitter, conn.frame_data.progressive_count = (float(jit[k, 0]), float(jit[k, 1])), 0
+    conn.draw()  # no sync: the gather of this launch is still in flight when the history is overwritten below
+    seen.add(dev.device_buffers().rgba8)
+    resume = np.random.default_rng(100 + k + 10 * rank).integers(0, 256, (rows, W, 4), dtype=np.uint8)
+    resume[..., 3] = 255
+    dev.call("rt_write_history_rgba8", resume.ctypes.data_as(C.c_void_p), resume.nbytes)
+    conn.frame_data.jitter, conn.frame_data.progressive_count = (float(jit[k + 1, 0]), float(jit[k + 1, 1])), 3
+    conn.draw()
+    dev.sync()
+    bufs = dev.device_buffers()
+    seen.add(bufs.rgba8)
+    direct = np.empty((rows, W, 4), np.uint8)
+    if hip.hipMemcpy(direct.ctypes.data_as(C.c_void_p), bufs.rgba8, direct.nbytes, 2) != 0:
+        ok = False
+    mine = target.read_rgba8()
+    if not np.array_equal(direct, mine):
+        ok = False
+        print("rank %d: rt_get_device_buffers does not name the current target (launch %d)" % (rank, k), flush=True)
+    if world == 1:  # the oracle's frame on top of that history
+        want = oracle.render(objects, count, cfg, jit[k + 1], 3, sky, rnd, history_rgba8=resume, want_hits=False).rgba8
+        if not np.array_equal(mine, want):
+            ok = False
+            print("rt_write_history_rgba8 with a communicator: %d texels differ" % int((mine != want).any(-1).sum()), flush=True)
+if len(seen) != 2:
+    ok = False
+    print("rank %d: the targets did not alternate (%d distinct)" % (rank, len(seen)), flush=True)
 # the watchdog calls: everything queued has completed after a sync; after rt_comm_abort the context is a single-GPU
 # context again and renders the whole frame by itself
 if not dev.comm_idle():

@@ -52,10 +52,16 @@ def grid_min_for(seed):
     return 1 if seed % 3 == 1 else 88
 
 
+def dirmask_for(seed):
+    """RT_OPT_DIRMASK* of a case: the direction-mask table at every resolution, for tiny scenes too; every fifth case off."""
+    return {N.RT_OPT_DIRMASK: 0 if seed % 5 == 4 else 1, N.RT_OPT_DIRMASK_MIN: 1,
+            N.RT_OPT_DIRMASK_K: (1, 2, 4, 8, 16)[(seed // 3) % 5], N.RT_OPT_DIRMASK_CELLS: (1, 27, 512, 4096)[(seed // 7) % 4]}
+
+
 def run(cases=100, first=0):
     dev = Device(0)
     sky = synth.procedural_skybox(128, 64)
-    bad = grids = 0
+    bad = grids = tables = 0
     for seed in range(first, first + cases):
         scene, size, jitter, slots, variant, tex_seed = random_case(seed)
         rnd = synth.random_texture(tex_seed)
@@ -65,6 +71,8 @@ def run(cases=100, first=0):
         dev.set_variant(variant)
         dev.set_option(N.RT_OPT_CULL, 2)
         dev.set_option(N.RT_OPT_GRID_MIN, grid_min_for(seed))
+        for opt, val in dirmask_for(seed).items():
+            dev.set_option(opt, val)
         target = RenderTarget.new(dev, size)
         rt = RandomTexture(dev)
         rt.write(rnd)
@@ -105,16 +113,19 @@ def run(cases=100, first=0):
                 print("  (in the %d-frame launch, first count %d, accum %d)" % (nf, pc0, accum), flush=True)
         if not ok:
             bad += 1
-            print("MISMATCH seed %d: %d objects, size %s, R %d, variant %d, slots %s, cull mismatches %d, grid cells %d"
-                  % (seed, len(scene.objects), size, scene.reflection_limit, variant, slots, st.last_cull_mismatches, st.grid_cells),
+            print("MISMATCH seed %d: %d objects, size %s, R %d, variant %d, slots %s, cull mismatches %d, grid cells %d, mask table %d x %d"
+                  % (seed, len(scene.objects), size, scene.reflection_limit, variant, slots, st.last_cull_mismatches, st.grid_cells,
+                     st.dirmask_cells, st.dirmask_bins),
                   flush=True)
         grids += st.last_stage == 3
+        tables += st.dirmask_cells != 0
         if (seed - first + 1) % 1000 == 0:  # a long soak must not look hung to the box's watchdog
             print("  ... %d cases, %d mismatching so far" % (seed - first + 1, bad), flush=True)
     dev.set_option(N.RT_OPT_CULL, 1)
     dev.set_option(N.RT_OPT_GRID_MIN, 88)
     dev.close()
-    print("fuzz: %d cases from seed %d (%d of them walked a sphere grid), %d mismatching" % (cases, first, grids, bad), flush=True)
+    print("fuzz: %d cases from seed %d (%d of them walked a sphere grid, %d used a direction-mask table), %d mismatching"
+          % (cases, first, grids, tables, bad), flush=True)
     return bad
 
 

@@ -14,7 +14,12 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from rsraytracingv3_amd._native import kernel_source_hash  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("dirs", nargs="+")
@@ -50,6 +55,7 @@ for d in args.dirs:
                 print(d, key, " ".join("%s=%.4g (n=%d)" % (c, merged[key][c], counts[key][c]) for c in sorted(acc[key])))
 if args.json:
     out = {
+        "kernel_source_sha256": kernel_source_hash(),  # bench.py quotes these counters only for a tree with the same sources
         "workload_key": {"width": args.width, "height": args.height, "objects": args.objects, "bounces": args.bounces,
                          "sky_width": args.sky_width, "frames_per_launch": args.frames_per_launch, "n_gpus": 1},
         "note": "separate rocprofv3 --pmc passes (tools/profile_round.sh), interquartile mean over the kernel's dispatches. "
