@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--batch-inflight", type=int, default=1,
                     help="RT_OPT_BATCH_INFLIGHT: multi-frame launches in flight (1 = one at a time, the library default: kernel "
                          "times do not overlap; 2 = the next launch renders while this one resolves, +1..4 %% throughput)")
-    ap.add_argument("--grid-min", type=int, default=0, help="RT_OPT_GRID_MIN: spheres from which a scene gets the sphere grid (0 = library default 88)")
+    ap.add_argument("--grid-min", type=int, default=0, help="RT_OPT_GRID_MIN: spheres from which a scene gets the sphere grid (0 = library default 129)")
     ap.add_argument("--dirmask", type=int, default=-1, help="RT_OPT_DIRMASK: 0 = secondary rays scan every sphere, 1 = direction-mask table (library default)")
     ap.add_argument("--dirmask-k", type=int, default=0, help="RT_OPT_DIRMASK_K (0 = library default)")
     ap.add_argument("--dirmask-cells", type=int, default=0, help="RT_OPT_DIRMASK_CELLS (0 = library default)")

@@ -281,16 +281,16 @@ enum {
                               (app.rs:208-254) and one 1080p frame leaves a fifth of the GPU idle during its
                               ramp-up and tail; the history is still updated strictly in frame order on the
                               context's stream.  1 = one launch at a time (kernel times do not overlap).     */
-  RT_OPT_GRID_MIN = 7,     /* scenes with at least this many spheres (default 88) get a uniform grid at the next
+  RT_OPT_GRID_MIN = 7,     /* scenes with at least this many spheres (default 129) get a uniform grid at the next
                               rt_set_scene: secondary rays then test the spheres of the cells they cross instead of
                               every sphere (ray.hlsl:97-107 scans linearly; the reference caps scenes at 80)       */
-  RT_OPT_DIRMASK = 9,      /* 1 (default): scenes of RT_OPT_DIRMASK_MIN .. 64 spheres (below the grid's threshold) get a table
+  RT_OPT_DIRMASK = 9,      /* 1 (default): scenes of RT_OPT_DIRMASK_MIN .. 128 spheres that get no grid receive a table
                               of candidate-sphere sets at the next rt_set_scene — [cell of the ray's origin][cube-map bin of
-                              its direction] -> 64-bit set — and secondary rays test only their set instead of every
+                              its direction] -> set of sphere slots — and secondary rays test only their set instead of every
                               sphere (ray.hlsl:97-107 scans linearly); rebuilt only when the sphere records change; 0: off */
-  RT_OPT_DIRMASK_MIN = 10,  /* fewest spheres that get the table (default 12)                                            */
+  RT_OPT_DIRMASK_MIN = 10,  /* fewest spheres that get the table (default 26)                                            */
   RT_OPT_DIRMASK_CELLS = 11,/* cells the table's grid aims at (default 4096; cubic cells, at most 64 per axis)           */
-  RT_OPT_DIRMASK_K = 12,    /* direction bins per cube-map face edge, 1..16 (default 8: 384 bins)                        */
+  RT_OPT_DIRMASK_K = 12,    /* direction bins per cube-map face edge, 1..16 (default 12: 864 bins)                       */
   RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 1): as RT_OPT_INFLIGHT,
                               each launch staging its samples in a buffer of its own; the history is updated in frame
                               order on the context's stream.  2 hides the resolve pass and the gap between launches
@@ -311,20 +311,21 @@ typedef struct rt_grid_info {
 RT355_API int rt_grid_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t min_spheres, rt_grid_info *info,
                                  uint32_t *cell_start, uint32_t cell_cap, uint16_t *items, uint32_t item_cap);
 
-/* The direction-mask table rt_set_scene builds for scenes of up to 64 spheres (RT_OPT_DIRMASK), exposed for inspection
+/* The direction-mask table rt_set_scene builds for scenes of up to 128 spheres (RT_OPT_DIRMASK), exposed for inspection
  * and for testing its sets without a GPU: host code only, the same entry function the device kernel runs.  spheres =
- * n x {cx, cy, cz, r*r}; table gets nx*ny*nz*bins 64-bit sets, [cell][bin] (when table_cap suffices; call with a null
- * table for the sizes).  info->enabled = 0 when the scene is not served.  rt_dirmask_lookup_host repeats a lane's lookup:
- * *served = 0 when the ray is not served by the table (origin outside the near box, direction not a unit vector — the
- * kernels then scan linearly), else *mask = the ray's candidate set (0 for a ray that misses the spheres' box). */
+ * n x {cx, cy, cz, r*r}; table gets nx*ny*nz*bins sets of `words` 64-bit words (1 for up to 64 spheres, else 2),
+ * [cell][bin][word] (when table_cap, in words, suffices; call with a null table for the sizes).  info->enabled = 0 when the
+ * scene is not served.  rt_dirmask_lookup_host repeats a lane's lookup: *served = 0 when the ray is not served by the table
+ * (origin outside the near box, direction not a unit vector — the kernels then scan linearly), else mask2[0..1] = the ray's
+ * candidate set (all zero for a ray that misses the spheres' box). */
 typedef struct rt_dirmask_info {
-  uint32_t enabled, nx, ny, nz, k, bins;
+  uint32_t enabled, nx, ny, nz, k, bins, words;
   float bmin[3], bmax[3], cell[3], inv_cell[3], near_min[3], near_max[3];
 } rt_dirmask_info;
 RT355_API int rt_dirmask_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t target_cells, uint32_t k,
                                     rt_dirmask_info *info, uint64_t *table, size_t table_cap);
 RT355_API int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, const float *origin3,
-                                     const float *direction3, uint64_t *mask, int *served);
+                                     const float *direction3, uint64_t *mask2, int *served);
 
 /* Device self-test hooks used by the parity tests: evaluate the device build of the
  * specified math function over n host values (op: 0 sin 1 cos 2 tan 3 asin 4 log2

@@ -1,7 +1,8 @@
 // rt_dirmask.h — candidate-sphere masks for secondary rays ("direction masks"), shared by host and device code.
 //
-// ray.hlsl:97-107 tests every object for every ray segment.  For scenes of up to 64 spheres rt355 keeps a table
-//     mask[cell of the ray's origin][bin of the ray's direction] -> 64-bit set of sphere slots
+// ray.hlsl:97-107 tests every object for every ray segment.  For scenes of up to 128 spheres (the reference's buffer
+// holds 80 objects) rt355 keeps a table
+//     mask[cell of the ray's origin][bin of the ray's direction] -> set of sphere slots (one or two 64-bit words)
 // built once per sphere geometry (dirmask_build_kernel, rt_kernels.hip): a secondary ray looks its set up with one
 // 8-byte load and tests only those spheres, in ascending slot order, with the arithmetic of the linear scan.  The
 // result is that of the linear scan because (1) a sphere gives the same hit key wherever it is tested, (2) ascending
@@ -35,7 +36,7 @@
 
 namespace rt355 {
 
-constexpr uint32_t kDirMaskMaxSpheres = 64;   // one 64-bit word per entry
+constexpr uint32_t kDirMaskMaxSpheres = 128;  // one or two 64-bit words per entry
 constexpr uint32_t kDirMaskMaxDim = 64;       // cells per axis
 constexpr uint32_t kDirMaskMaxK = 16;         // bins per cube-map face edge
 
@@ -43,11 +44,12 @@ struct DirMaskParams {
   uint32_t enabled;
   uint32_t nx, ny, nz;          // cells per axis
   uint32_t k, bins;             // bins per face edge; 6 * k * k
+  uint32_t words;               // 64-bit words per entry: 1 (up to 64 spheres) or 2
   float half_k;                 // k / 2
   float bmin[3], bmax[3];       // the box B
   float cell[3], inv_cell[3];   // cell edge per axis (equal up to rounding: cubic cells) and its reciprocal
   float near_min[3], near_max[3];
-  const unsigned long long *table;  // [cell][bin], device memory
+  const unsigned long long *table;  // [cell][bin][words], device memory
 };
 
 // Bin of a direction (any non-zero vector): face = 2 * major axis + (major component < 0), (u, v) = the components
@@ -68,8 +70,9 @@ RT_HD uint32_t dirmask_bin(f3 d, float inv_major, uint32_t k, float half_k) {
   // (u * inv + 1) * k / 2 in [0, k]; the conversion truncates (and sends negatives and NaN to 0), the last bin keeps k
   const float fu = fmaf(u * inv_major, half_k, half_k), fv = fmaf(v * inv_major, half_k, half_k);
   uint32_t bu = static_cast<uint32_t>(fmaxf(fu, 0.0f)), bv = static_cast<uint32_t>(fmaxf(fv, 0.0f));
-  bu = bu < k ? bu : k - 1u;
-  bv = bv < k ? bv : k - 1u;
+  const uint32_t last = k - 1u;
+  bu = bu < last ? bu : last;  // one v_min_u32 each
+  bv = bv < last ? bv : last;
   return (face * k + bv) * k + bu;
 }
 
@@ -79,16 +82,17 @@ RT_HD uint32_t dirmask_cell(const DirMaskParams &dm, f3 p) {
               fz = (p.z - dm.bmin[2]) * dm.inv_cell[2];
   uint32_t ix = static_cast<uint32_t>(fmaxf(fx, 0.0f)), iy = static_cast<uint32_t>(fmaxf(fy, 0.0f)),
            iz = static_cast<uint32_t>(fmaxf(fz, 0.0f));
-  ix = ix < dm.nx ? ix : dm.nx - 1u;
-  iy = iy < dm.ny ? iy : dm.ny - 1u;
-  iz = iz < dm.nz ? iz : dm.nz - 1u;
+  const uint32_t lx = dm.nx - 1u, ly = dm.ny - 1u, lz = dm.nz - 1u;
+  ix = ix < lx ? ix : lx;  // one v_min_u32 each
+  iy = iy < ly ? iy : ly;
+  iz = iz < lz ? iz : lz;
   return (iz * dm.ny + iy) * dm.nx + ix;
 }
 
-// One table entry: the set of spheres {c, r_reg} (reg[i] = {cx, cy, cz, r_reg}, n <= 64) a ray from cell `cell` with a
-// direction of bin `bin` can be accepted by.  Plain float arithmetic with wide margins; host and device may round
-// differently — both results are conservative.
-RT_HD unsigned long long dirmask_entry(const DirMaskParams &dm, uint32_t cell, uint32_t bin, const float4 *reg, uint32_t n) {
+// One table entry: the set of spheres {c, r_reg} (reg[i] = {cx, cy, cz, r_reg}, n <= 128) a ray from cell `cell` with a
+// direction of bin `bin` can be accepted by, as two 64-bit words (out[1] = 0 for n <= 64).  Plain float arithmetic with
+// wide margins; host and device may round differently — both results are conservative.
+RT_HD void dirmask_entry(const DirMaskParams &dm, uint32_t cell, uint32_t bin, const float4 *reg, uint32_t n, unsigned long long out[2]) {
   const uint32_t ix = cell % dm.nx, iy = (cell / dm.nx) % dm.ny, iz = cell / (dm.nx * dm.ny);
   const f3 p = mk3(dm.bmin[0] + (static_cast<float>(ix) + 0.5f) * dm.cell[0], dm.bmin[1] + (static_cast<float>(iy) + 0.5f) * dm.cell[1],
                    dm.bmin[2] + (static_cast<float>(iz) + 0.5f) * dm.cell[2]);
@@ -122,7 +126,7 @@ RT_HD unsigned long long dirmask_entry(const DirMaskParams &dm, uint32_t cell, u
   cos_theta = fminf(cos_theta, 1.0f);
   const float sin_theta0 = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
   const float ct = cos_theta * 0.999998f - sin_theta0 * 2e-3f, st = sin_theta0 * 0.999998f + cos_theta * 2e-3f;  // cos / sin of theta + 2e-3
-  unsigned long long m = 0ull;
+  unsigned long long m0 = 0ull, m1 = 0ull;
   for (uint32_t i = 0; i < n; ++i) {
     const float4 g = reg[i];
     const float vx = g.x - p.x, vy = g.y - p.y, vz = g.z - p.z;
@@ -138,13 +142,15 @@ RT_HD unsigned long long dirmask_entry(const DirMaskParams &dm, uint32_t cell, u
       // theta + phi >= pi/2 + ... : cos_sum is decreasing in both on [0, pi]; theta < pi/2 and phi <= pi/2 keep the sum below pi
       in = !(cos_ang < cos_sum - 1e-4f);
     }
-    m |= in ? (1ull << i) : 0ull;
+    if (i < 64u) m0 |= in ? (1ull << i) : 0ull;
+    else m1 |= in ? (1ull << (i - 64u)) : 0ull;
   }
-  return m;
+  out[0] = m0;
+  out[1] = m1;
 }
 
 // Host side: resolution and boxes for n spheres {cx, cy, cz, r*r}; reg[i] receives {c, r_reg}.  Returns a disabled
-// plan for scenes the table does not serve (no sphere, more than 64, non-finite data).  `target_cells`: cells aimed at
+// plan for scenes the table does not serve (no sphere, more than 128, non-finite data).  `target_cells`: cells aimed at
 // (cubic cells, 1..kDirMaskMaxDim per axis); `k`: bins per face edge.
 inline DirMaskParams dirmask_plan(const float4 *sph, uint32_t n, uint32_t target_cells, uint32_t k, float4 *reg) {
   DirMaskParams dm{};
@@ -216,6 +222,7 @@ inline DirMaskParams dirmask_plan(const float4 *sph, uint32_t n, uint32_t target
   dm.nz = dims[2];
   dm.k = k;
   dm.bins = 6u * k * k;
+  dm.words = n > 64u ? 2u : 1u;
   dm.half_k = 0.5f * static_cast<float>(k);
   for (uint32_t i = 0; i < n; ++i) reg[i] = make_float4(sph[i].x, sph[i].y, sph[i].z, static_cast<float>(rr[i] * 1.0001));
   dm.enabled = 1;

@@ -435,10 +435,10 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
 }
 
 // ---- direction masks (rt_dirmask.h): secondary rays of scenes with up to 64 spheres --------------------------------
-// The candidate set of this lane's ray as two 32-bit words (0 for lanes without a ray, and for rays that miss the box of
-// the registered balls).  Returns false — wave-uniform — when some live lane's ray is not served by the table (origin
+// The candidate set of this lane's ray as 32-bit words (two, or four for scenes of 65..128 spheres; 0 for lanes without a
+// ray, and for rays that miss the box of the registered balls).  Returns false — wave-uniform — when some live lane's ray is not served by the table (origin
 // outside the near box, direction not a unit vector, NaN): the wave then scans linearly as before.
-__device__ __forceinline__ bool dirmask_lookup(const DirMaskParams &dm, f3 o, f3 d, bool alive, uint32_t &lo, uint32_t &hi) {
+__device__ __forceinline__ bool dirmask_lookup(const DirMaskParams &dm, f3 o, f3 d, bool alive, uint32_t (&m)[4]) {
   const bool served = (fabsf(dot3(d, d) - 1.0f) <= 4e-6f) & (o.x >= dm.near_min[0]) & (o.x <= dm.near_max[0]) &
                       (o.y >= dm.near_min[1]) & (o.y <= dm.near_max[1]) & (o.z >= dm.near_min[2]) & (o.z <= dm.near_max[2]);
   if (__builtin_amdgcn_ballot_w64(alive & !served) != 0ull) return false;
@@ -463,17 +463,28 @@ __device__ __forceinline__ bool dirmask_lookup(const DirMaskParams &dm, f3 o, f3
   const uint32_t cell = dirmask_cell(dm, p);
   const float inv_major = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
   const uint32_t bin = dirmask_bin(d, inv_major, dm.k, dm.half_k);
-  unsigned long long m = 0ull;
-  if (alive & reaches) m = dm.table[static_cast<size_t>(cell) * dm.bins + bin];
-  lo = static_cast<uint32_t>(m);
-  hi = static_cast<uint32_t>(m >> 32);
+  m[0] = m[1] = m[2] = m[3] = 0u;
+  const size_t entry = static_cast<size_t>(cell) * dm.bins + bin;
+  if (dm.words == 1u) {  // wave-uniform
+    if (alive & reaches) {
+      const uint2 w = *reinterpret_cast<const uint2 *>(dm.table + entry);
+      m[0] = w.x;
+      m[1] = w.y;
+    }
+  } else if (alive & reaches) {
+    const uint4 w = *reinterpret_cast<const uint4 *>(dm.table + 2u * entry);
+    m[0] = w.x;
+    m[1] = w.y;
+    m[2] = w.z;
+    m[3] = w.w;
+  }
   return true;
 }
 
 // The sphere part of ray.hlsl:97-107 over this lane's candidate set, lanes diverge: ascending slots, the arithmetic of
 // the linear scan, strict '<' — the lexicographic (key, slot) minimum over the set, which is the linear scan's result
 // because the set holds every sphere the scan could accept (rt_dirmask.h).
-__device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restrict__ sph, f3 o, f3 d, uint32_t lo, uint32_t hi) {
+__device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restrict__ sph, f3 o, f3 d, uint32_t (&m)[4], uint32_t words) {
   uint32_t best_key = kNoHitKey;
   int slot = -1;
 #define RT_MASK_WORD(word_, base)                                                                  \
@@ -490,8 +501,12 @@ __device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restric
       best_key = min(best_key, key);                                                               \
     }                                                                                              \
   }
-  RT_MASK_WORD(lo, 0u)
-  RT_MASK_WORD(hi, 32u)
+  RT_MASK_WORD(m[0], 0u)
+  RT_MASK_WORD(m[1], 32u)
+  if (words > 1u) {  // wave-uniform: scenes of 65..128 spheres
+    RT_MASK_WORD(m[2], 64u)
+    RT_MASK_WORD(m[3], 96u)
+  }
 #undef RT_MASK_WORD
   return SphereHit{best_key, slot};
 }
@@ -746,9 +761,9 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
     RT_REQUEST_X2
     if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     RT_PH_MARK(3)
-  } else if (uint32_t lo = 0u, hi = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, lo, hi)) {
+  } else if (uint32_t cand[4]; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, cand)) {
     // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
-    const SphereHit sh = scan_spheres_masked(sv.sph, s.o, s.d, lo, hi);
+    const SphereHit sh = scan_spheres_masked(sv.sph, s.o, s.d, cand, sv.dm->words);
     if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
       const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
       if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
@@ -809,9 +824,9 @@ __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FramePa
       h = finish_hit(sv, sh, s.o, s.d);
     }
     RT_PH_MARK(0)
-  } else if (uint32_t lo = 0u, hi = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, lo, hi)) {
+  } else if (uint32_t cand[4]; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, cand)) {
     // secondary rays of a small scene: every lane tests its own candidate set
-    const SphereHit sh = scan_spheres_masked(sv.sph, s.o, s.d, lo, hi);
+    const SphereHit sh = scan_spheres_masked(sv.sph, s.o, s.d, cand, sv.dm->words);
     if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
       const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
       if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
@@ -1571,11 +1586,14 @@ __global__ void __launch_bounds__(256) cull_slabs_kernel(DeviceScene sc, FramePa
 __global__ void __launch_bounds__(256) dirmask_build_kernel(DirMaskParams dm, const float4 *reg, uint32_t n, unsigned long long *table,
                                                             unsigned long long entries) {
   __shared__ float4 s_reg[kDirMaskMaxSpheres];
-  if (threadIdx.x < n) s_reg[threadIdx.x] = reg[threadIdx.x];
+  if (threadIdx.x < n) s_reg[threadIdx.x] = reg[threadIdx.x];  // n <= 128 < 256 threads
   __syncthreads();
   const unsigned long long e = static_cast<unsigned long long>(blockIdx.x) * 256ull + threadIdx.x;
   if (e >= entries) return;
-  table[e] = dirmask_entry(dm, static_cast<uint32_t>(e / dm.bins), static_cast<uint32_t>(e % dm.bins), s_reg, n);
+  unsigned long long w[2];
+  dirmask_entry(dm, static_cast<uint32_t>(e / dm.bins), static_cast<uint32_t>(e % dm.bins), s_reg, n, w);
+  table[e * dm.words] = w[0];
+  if (dm.words > 1u) table[e * dm.words + 1u] = w[1];
 }
 
 // Second pass of a batch launch (rt_render_frames): folds the batch's float samples into the history
@@ -1738,7 +1756,7 @@ int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfi
     // resident-wave shape (2) is never the fastest since the primary-ray culling, which it cannot use; selectable.
     // The streamed shape (4) only draws level from 16 frames per launch up; selectable.
     const uint64_t enough = fp.batch > 1u ? 20000ull : 24000ull;  // single frames: a whole 1080p frame (32 400 tiles) re-packs, half of one renders as tiles
-    variant = (sc.n_sph_pad > 128u || tiles < enough || sc.grid.enabled) ? 0 : 3;
+    variant = (sc.n_sph_pad > 136u || tiles < enough || sc.grid.enabled) ? 0 : 3;  // up to 128 spheres (+ 8 padding records)
 #if RT_STREAM_MIN_TILES
     if (variant == 3 && tiles >= RT_STREAM_MIN_TILES && sample_only(fp)) variant = 4;
 #endif

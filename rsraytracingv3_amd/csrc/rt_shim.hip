@@ -122,16 +122,19 @@ struct rt_context {
   uint64_t prep_seen[kMaxInflight] = {};        // generation each render stream has already waited for
   // direction masks (rt_dirmask.h): table of candidate-sphere sets for the secondary rays of scenes with up to 64 spheres
   int dirmask_on = 1;            // RT_OPT_DIRMASK
-  int dirmask_min_spheres = 12;  // RT_OPT_DIRMASK_MIN: smaller scenes scan linearly (the lookup costs more than their scan)
+  int dirmask_min_spheres = 26;  // RT_OPT_DIRMASK_MIN: smaller scenes scan linearly (the lookup costs more than their scan: A/B on one
+                                 // device, table / linear in Grays/s: 16 spheres 57.4 / 59.9, 24: 53.0 / 53.0, 28: 51.6 / 49.6, 32: 51.7 / 49.7,
+                                 // 48: 49.2 / 44.0, 64: 46.9 / 38.7)
   int dirmask_cells = 4096;      // RT_OPT_DIRMASK_CELLS: cells aimed at
-  int dirmask_k = 8;             // RT_OPT_DIRMASK_K: bins per cube-map face edge
+  int dirmask_k = 12;            // RT_OPT_DIRMASK_K: bins per cube-map face edge
   unsigned long long *d_dirmask = nullptr;
   size_t dirmask_cap = 0;        // in entries
   float4 *d_dirmask_reg = nullptr;
   std::vector<float4> dirmask_built_for;  // sphere records (+ one record of options) the table on the device was built from
-  int grid_min_spheres = 88;   // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid (A/B on one
-                               // device, tools/grid_threshold_sweep.sh, Grays/s linear / grid: 64 spheres 40.2 / 32.4, 80: 47.5 /
-                               // 47.3, 88: 45.2 / 46.3, 96: 41.9 / 45.5, 128: 33.7 / 40.6)
+  int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid; up to 128 spheres the
+                               // direction-mask table serves (A/B on one device, tools/dirmask_sweep.sh, Grays/s table / grid / linear:
+                               // 80 spheres 60.0 / 47.3 / 45.7, 96: 53.8 / 45.3 / 40.3, 128: 40.6 / 40.3 / 30.6 before the re-packing
+                               // shape took 128-sphere scenes; round 2's linear / grid crossover was 88)
   hipStream_t render_stream[kMaxInflight] = {};
   hipEvent_t prep_done = nullptr;  // (the renders and resolves are joined on the per-launch timing events)
   bool resolve_pending[kMaxInflight] = {};  // pipe_samples[i] has been written; its resolve is ev_resolved[resolve_slot[i]]
@@ -321,7 +324,7 @@ int read_back(rt_context *ctx, const T *src, void *dst, size_t bytes, size_t ele
 // The direction-mask table of the current spheres (rt_dirmask.h), rebuilt on the device only when the sphere records
 // or the table's options changed (a moving camera re-sends the same objects every frame, connection.rs:373-385).
 // Leaves ctx->scene.dm disabled when the scene is not served.
-constexpr size_t kDirMaskMaxEntries = 8u << 20;  // 64 MB
+constexpr size_t kDirMaskMaxEntries = 8u << 20;  // 64 MB of one-word entries (128 MB with two words)
 int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
   float4 reg[kDirMaskMaxSpheres];
   uint32_t target = static_cast<uint32_t>(ctx->dirmask_cells);
@@ -335,6 +338,7 @@ int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
   if (entries > kDirMaskMaxEntries) return RT_OK;
   std::vector<float4> key(sph, sph + n);
   key.push_back(make_float4(static_cast<float>(dm.nx), static_cast<float>(dm.ny), static_cast<float>(dm.nz), static_cast<float>(dm.k)));
+  key.push_back(make_float4(dm.cell[0], dm.bmin[0], dm.bmin[1], dm.bmin[2]));
   const bool same = ctx->d_dirmask && key.size() == ctx->dirmask_built_for.size() &&
                     std::memcmp(key.data(), ctx->dirmask_built_for.data(), key.size() * sizeof(float4)) == 0;
   if (!same) {
@@ -343,7 +347,7 @@ int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
       (void)hipFree(ctx->d_dirmask);
       ctx->d_dirmask = nullptr;
       ctx->dirmask_cap = 0;
-      RT_HIP(ctx, hipMalloc(&ctx->d_dirmask, entries * sizeof(unsigned long long)));
+      RT_HIP(ctx, hipMalloc(&ctx->d_dirmask, entries * 2u * sizeof(unsigned long long)));  // room for two-word entries
       ctx->dirmask_cap = entries;
     }
     if (!ctx->d_dirmask_reg) RT_HIP(ctx, hipMalloc(&ctx->d_dirmask_reg, kDirMaskMaxSpheres * sizeof(float4)));
@@ -746,6 +750,7 @@ static DirMaskParams dirmask_from_info(const rt_dirmask_info *info) {
   dm.nz = info->nz;
   dm.k = info->k;
   dm.bins = info->bins;
+  dm.words = info->words;
   dm.half_k = 0.5f * static_cast<float>(info->k);
   for (int a = 0; a < 3; ++a) {
     dm.bmin[a] = info->bmin[a];
@@ -774,6 +779,7 @@ int rt_dirmask_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32
   info->nz = dm.nz;
   info->k = dm.k;
   info->bins = dm.bins;
+  info->words = dm.words;
   for (int a = 0; a < 3; ++a) {
     info->bmin[a] = dm.bmin[a];
     info->bmax[a] = dm.bmax[a];
@@ -783,18 +789,22 @@ int rt_dirmask_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32
     info->near_max[a] = dm.near_max[a];
   }
   const size_t entries = static_cast<size_t>(dm.nx) * dm.ny * dm.nz * dm.bins;
-  if (table && table_cap >= entries)
-    for (size_t e = 0; e < entries; ++e)
-      table[e] = dirmask_entry(dm, static_cast<uint32_t>(e / dm.bins), static_cast<uint32_t>(e % dm.bins), reg, n_spheres);
+  if (table && table_cap >= entries * dm.words)
+    for (size_t e = 0; e < entries; ++e) {
+      unsigned long long w[2];
+      dirmask_entry(dm, static_cast<uint32_t>(e / dm.bins), static_cast<uint32_t>(e % dm.bins), reg, n_spheres, w);
+      table[e * dm.words] = w[0];
+      if (dm.words > 1u) table[e * dm.words + 1u] = w[1];
+    }
   return RT_OK;
 }
 
 int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, const float *origin3, const float *direction3,
-                           uint64_t *mask, int *served) {
-  if (!info || !table || !origin3 || !direction3 || !mask || !served || !info->enabled) return RT_ERR_INVALID_ARGUMENT;
+                           uint64_t *mask2, int *served) {
+  if (!info || !table || !origin3 || !direction3 || !mask2 || !served || !info->enabled) return RT_ERR_INVALID_ARGUMENT;
   const DirMaskParams dm = dirmask_from_info(info);
   const f3 o = mk3(origin3[0], origin3[1], origin3[2]), d = mk3(direction3[0], direction3[1], direction3[2]);
-  *mask = 0;
+  mask2[0] = mask2[1] = 0;
   *served = 0;
   // the lane's arithmetic (dirmask_lookup in rt_kernels.hip), with an IEEE reciprocal where the device uses v_rcp_f32
   const bool ok = (fabsf(dot3(d, d) - 1.0f) <= 4e-6f) && (o.x >= dm.near_min[0]) && (o.x <= dm.near_max[0]) && (o.y >= dm.near_min[1]) &&
@@ -819,7 +829,9 @@ int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, c
   }
   const uint32_t cell = dirmask_cell(dm, p);
   const float inv_major = 1.0f / fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-  *mask = table[static_cast<size_t>(cell) * dm.bins + dirmask_bin(d, inv_major, dm.k, dm.half_k)];
+  const size_t entry = static_cast<size_t>(cell) * dm.bins + dirmask_bin(d, inv_major, dm.k, dm.half_k);
+  mask2[0] = table[entry * dm.words];
+  if (dm.words > 1u) mask2[1] = table[entry * dm.words + 1u];
   return RT_OK;
 }
 

@@ -23,7 +23,7 @@ def build(spheres, target_cells, k):
     assert lib.rt_dirmask_build_host(sph.ctypes.data_as(C.c_void_p), len(sph), target_cells, k, C.byref(info), None, 0) == 0
     if not info.enabled:
         return info, None
-    table = np.zeros(info.nx * info.ny * info.nz * info.bins, np.uint64)
+    table = np.zeros(info.nx * info.ny * info.nz * info.bins * info.words, np.uint64)
     assert lib.rt_dirmask_build_host(sph.ctypes.data_as(C.c_void_p), len(sph), target_cells, k, C.byref(info),
                                      table.ctypes.data_as(C.c_void_p), table.size) == 0
     return info, table
@@ -33,10 +33,10 @@ def lookup(info, table, o, d):
     lib = N.load()
     o = np.ascontiguousarray(o, np.float32)
     d = np.ascontiguousarray(d, np.float32)
-    mask, served = C.c_uint64(0), C.c_int(0)
+    mask, served = (C.c_uint64 * 2)(0, 0), C.c_int(0)
     assert lib.rt_dirmask_lookup_host(C.byref(info), table.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p),
-                                      d.ctypes.data_as(C.c_void_p), C.byref(mask), C.byref(served)) == 0
-    return int(mask.value), bool(served.value)
+                                      d.ctypes.data_as(C.c_void_p), mask, C.byref(served)) == 0
+    return int(mask[0]) | (int(mask[1]) << 64), bool(served.value)
 
 
 def sphere_records(scene):
@@ -96,6 +96,35 @@ def test_sets_hold_for_other_views_and_scenes():
     check_scene(small, (64, 36), 2048, 8)
 
 
+def test_the_reference_80_slot_scene_uses_two_word_sets():
+    """connection.rs keeps 80 object slots, the unused ones zero-filled: radius-0 spheres at the origin the shader still
+    tests.  64 spheres + 15 of those = 79 spheres -> two 64-bit words per entry."""
+    scene = cases.headline_scene(8)
+    w, h = 80, 45
+    sky, rnd = cases.inputs(64, 32)
+    objects = scene.as_bytes(w, h)[0]
+    frame, rays = oracle.render_with_rays(objects, 80, scene.config_bytes(w, h), (0.0, 0.0), 0, sky, rnd, threads=4)
+    import struct
+    recs, slots = [], {}
+    for i in range(80):
+        cx, cy, cz = struct.unpack_from("<fff", objects, 112 * i + 64)   # include/rt355_layout.h: geometry.center @64
+        option = struct.unpack_from("<I", objects, 112 * i + 48)[0]      # geometry.option @48
+        f32 = struct.unpack_from("<f", objects, 112 * i + 92)[0]         # geometry.f32_data @92
+        if option == 0:
+            slots[i] = len(recs)
+            recs.append((cx, cy, cz, np.float32(f32) * np.float32(f32)))
+    assert len(recs) == 79
+    info, table = build(np.array(recs, np.float32), 1024, 6)
+    assert info.enabled and info.words == 2
+    for y in range(h):
+        for x in range(w):
+            for i in range(1, int(frame.segments[y, x])):
+                mask, served = lookup(info, table, rays[y, x, i, :3], rays[y, x, i, 3:])
+                obj = int(frame.hits[y, x, i])
+                if served and obj in slots:
+                    assert (mask >> slots[obj]) & 1
+
+
 def test_rays_the_table_does_not_serve_are_flagged():
     sph, _ = sphere_records(cases.headline_scene(2))
     info, table = build(sph, 256, 4)
@@ -112,7 +141,7 @@ def test_rays_the_table_does_not_serve_are_flagged():
 def test_scenes_that_are_not_served():
     info, table = build(np.zeros((0, 4), np.float32), 256, 4)
     assert not info.enabled and table is None
-    too_many = np.tile(np.array([[0, 0, 0, 1]], np.float32), (65, 1))
+    too_many = np.tile(np.array([[0, 0, 0, 1]], np.float32), (129, 1))
     assert not build(too_many, 256, 4)[0].enabled
     bad = np.array([[0, 0, 0, 1], [np.inf, 0, 0, 1]], np.float32)
     assert not build(bad, 256, 4)[0].enabled

@@ -685,3 +685,64 @@ def test_degenerate_spheres_around_ray_origins(device, variant):
         ref = run_oracle(scene, size, sky, rnd, jitter, max_objects="live")
         assert_frame_equal(outs[0], ref)
         assert st.last_segments == int(ref.segments.sum())
+
+
+@pytest.mark.parametrize("variant", [0, 2, 3])
+@pytest.mark.parametrize("case", ["headline_live", "reference_80_slots", "stress_100", "stress_128", "inside_the_scene"])
+def test_direction_mask_table_never_changes_a_frame(device, variant, case):
+    """rt_dirmask.h: secondary rays of scenes with 26..128 spheres test only the spheres of their table entry.  The frame
+    must be the oracle's (= the linear scan's) bit for bit, with the table at several resolutions, one and two 64-bit
+    words per entry (the reference's 80 slots hold 79 spheres), and with RT_OPT_CULL = 2 the kernel re-scans every
+    lookup linearly and counts disagreements: zero."""
+    from rsraytracingv3_amd.scene import Camera
+    size, jitter, slots = (200, 112), (0.3, -0.2), "live"
+    if case == "headline_live":
+        scene = cases.headline_scene(8)
+    elif case == "reference_80_slots":
+        scene, slots = cases.headline_scene(8), None
+    elif case == "stress_100":
+        scene = cases.stress_scene(100, 6)
+        scene.camera = Camera((60.0, 40.0, 60.0), (0.5, -0.8, 0.0), 70.0)
+    elif case == "stress_128":
+        scene = cases.stress_scene(128, 6)
+        scene.camera = Camera((60.0, 40.0, 60.0), (0.5, -0.8, 0.0), 70.0)
+    else:  # camera between the spheres, looking along the ground: long shallow rays, origins outside the spheres' box
+        scene = cases.headline_scene(8)
+        scene.camera = Camera((70.0, 4.0, 10.0), (0.02, -1.6, 0.0), 80.0)
+    sky, rnd = cases.inputs(64, 32)
+    ref = run_oracle(scene, size, sky, rnd, jitter, max_objects=slots)
+    try:
+        for k, cells in ((12, 4096), (3, 64), (16, 512)):
+            device.set_option(N.RT_OPT_DIRMASK, 1)
+            device.set_option(N.RT_OPT_DIRMASK_K, k)
+            device.set_option(N.RT_OPT_DIRMASK_CELLS, cells)
+            device.set_option(N.RT_OPT_CULL, 2)
+            outs, st = run_gpu(device, scene, size, sky, rnd, jitter, max_objects=slots, variant=variant)
+            assert st.dirmask_cells > 0 and st.dirmask_bins == 6 * k * k, "the scene got no table"
+            assert st.last_cull_mismatches == 0
+            assert_frame_equal(outs[0], ref)
+        device.set_option(N.RT_OPT_DIRMASK, 0)
+        outs, st = run_gpu(device, scene, size, sky, rnd, jitter, max_objects=slots, variant=variant)
+        assert st.dirmask_cells == 0
+        assert_frame_equal(outs[0], ref)
+    finally:
+        device.set_option(N.RT_OPT_DIRMASK, 1)
+        device.set_option(N.RT_OPT_DIRMASK_K, 12)
+        device.set_option(N.RT_OPT_DIRMASK_CELLS, 4096)
+        device.set_option(N.RT_OPT_CULL, 1)
+
+
+def test_direction_mask_table_is_kept_while_the_spheres_stay(device):
+    """A moving camera re-sends the same objects every frame (connection.rs:373-385): the table is rebuilt only when a
+    sphere record changes, and frames stay the oracle's through both."""
+    scene = cases.headline_scene(4)
+    size = (160, 90)
+    sky, rnd = cases.inputs(64, 32)
+    for step in range(3):
+        scene.camera.position = (55.0 + 3.0 * step, 65.0, 55.0)
+        if step == 2:
+            c = scene.objects[5].geometry.center
+            scene.objects[5].geometry.center = (c[0] + 1.5, c[1], c[2] - 0.5)
+        outs, st = run_gpu(device, scene, size, sky, rnd, (0.1, 0.1), max_objects="live")
+        assert st.dirmask_cells > 0
+        assert_frame_equal(outs[0], run_oracle(scene, size, sky, rnd, (0.1, 0.1), max_objects="live"))
