@@ -45,6 +45,7 @@ struct DirMaskParams {
   uint32_t nx, ny, nz;          // cells per axis
   uint32_t k, bins;             // bins per face edge; 6 * k * k
   uint32_t words;               // 64-bit words per entry: 1 (up to 64 spheres) or 2
+  uint32_t entries;             // nx * ny * nz * bins; the device table holds one more, all-zero entry at this index
   float half_k;                 // k / 2
   float bmin[3], bmax[3];       // the box B
   float cell[3], inv_cell[3];   // cell edge per axis (equal up to rounding: cubic cells) and its reciprocal
@@ -223,6 +224,7 @@ inline DirMaskParams dirmask_plan(const float4 *sph, uint32_t n, uint32_t target
   dm.k = k;
   dm.bins = 6u * k * k;
   dm.words = n > 64u ? 2u : 1u;
+  dm.entries = dm.nx * dm.ny * dm.nz * dm.bins;
   dm.half_k = 0.5f * static_cast<float>(k);
   for (uint32_t i = 0; i < n; ++i) reg[i] = make_float4(sph[i].x, sph[i].y, sph[i].z, static_cast<float>(rr[i] * 1.0001));
   dm.enabled = 1;

@@ -77,6 +77,9 @@ constexpr int kTile = 8;  // 8x8 pixels per tile / wave
                        // 32.5 / 33.1 at 5, 1 wave 32.7 / 30.5, 8 waves 27.0 / 27.5 — hence 2 waves, and the register
                        // budget by launch kind
 #endif
+#ifndef RT_MASK_PIPELINE
+#define RT_MASK_PIPELINE 1  // direction-mask scans: request the next candidate's record before the current one is tested
+#endif
 #ifndef RT_PACK_HITS
 #define RT_PACK_HITS 1  // re-packing shape: pack the paths that hit between the scan and the shading (0: after the shading)
 #endif
@@ -435,10 +438,11 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
 }
 
 // ---- direction masks (rt_dirmask.h): secondary rays of scenes with up to 64 spheres --------------------------------
-// The candidate set of this lane's ray as 32-bit words (two, or four for scenes of 65..128 spheres; 0 for lanes without a
-// ray, and for rays that miss the box of the registered balls).  Returns false — wave-uniform — when some live lane's ray is not served by the table (origin
+// The table entry of this lane's ray.  Lanes without a ray, and rays that miss the box of the registered balls, get the
+// index of the table's extra all-zero entry (the one past the last cell), so that every lane can load its set without a
+// branch around the load.  Returns false — wave-uniform — when some live lane's ray is not served by the table (origin
 // outside the near box, direction not a unit vector, NaN): the wave then scans linearly as before.
-__device__ __forceinline__ bool dirmask_lookup(const DirMaskParams &dm, f3 o, f3 d, bool alive, uint32_t (&m)[4]) {
+__device__ __forceinline__ bool dirmask_lookup(const DirMaskParams &dm, f3 o, f3 d, bool alive, uint32_t &entry) {
   const bool served = (fabsf(dot3(d, d) - 1.0f) <= 4e-6f) & (o.x >= dm.near_min[0]) & (o.x <= dm.near_max[0]) &
                       (o.y >= dm.near_min[1]) & (o.y <= dm.near_max[1]) & (o.z >= dm.near_min[2]) & (o.z <= dm.near_max[2]);
   if (__builtin_amdgcn_ballot_w64(alive & !served) != 0ull) return false;
@@ -463,35 +467,20 @@ __device__ __forceinline__ bool dirmask_lookup(const DirMaskParams &dm, f3 o, f3
   const uint32_t cell = dirmask_cell(dm, p);
   const float inv_major = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
   const uint32_t bin = dirmask_bin(d, inv_major, dm.k, dm.half_k);
-  m[0] = m[1] = m[2] = m[3] = 0u;
-  const size_t entry = static_cast<size_t>(cell) * dm.bins + bin;
-  if (dm.words == 1u) {  // wave-uniform
-    if (alive & reaches) {
-      const uint2 w = *reinterpret_cast<const uint2 *>(dm.table + entry);
-      m[0] = w.x;
-      m[1] = w.y;
-    }
-  } else if (alive & reaches) {
-    const uint4 w = *reinterpret_cast<const uint4 *>(dm.table + 2u * entry);
-    m[0] = w.x;
-    m[1] = w.y;
-    m[2] = w.z;
-    m[3] = w.w;
-  }
+  entry = (alive & reaches) ? cell * dm.bins + bin : dm.entries;
   return true;
 }
 
 // The sphere part of ray.hlsl:97-107 over this lane's candidate set, lanes diverge: ascending slots, the arithmetic of
 // the linear scan, strict '<' — the lexicographic (key, slot) minimum over the set, which is the linear scan's result
 // because the set holds every sphere the scan could accept (rt_dirmask.h).
-__device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restrict__ sph, f3 o, f3 d, uint32_t (&m)[4], uint32_t words) {
+template <int WORDS32>
+__device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restrict__ sph, f3 o, f3 d, uint32_t m0, uint32_t m1,
+                                                         uint32_t m2 = 0u, uint32_t m3 = 0u) {
   uint32_t best_key = kNoHitKey;
   int slot = -1;
-#define RT_MASK_WORD(word_, base)                                                                  \
-  while (word_ != 0u) {                                                                            \
-    const uint32_t i = (base) + static_cast<uint32_t>(__builtin_ctz(word_));                       \
-    word_ &= word_ - 1u;                                                                           \
-    const float4 g = sph[i];                                                                       \
+#define RT_MASK_TEST(g, i)                                                                         \
+  {                                                                                                \
     const float nx = o.x - g.x, ny = o.y - g.y, nz = o.z - g.z;                                    \
     const float dn = fmaf(d.z, nz, fmaf(d.y, ny, d.x * nx));                                       \
     const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));                    \
@@ -501,13 +490,44 @@ __device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restric
       best_key = min(best_key, key);                                                               \
     }                                                                                              \
   }
-  RT_MASK_WORD(m[0], 0u)
-  RT_MASK_WORD(m[1], 32u)
-  if (words > 1u) {  // wave-uniform: scenes of 65..128 spheres
-    RT_MASK_WORD(m[2], 64u)
-    RT_MASK_WORD(m[3], 96u)
+  // One sphere per trip, two trips per loop turn with the records in alternating registers: the NEXT candidate's record
+  // is requested before this one is tested, so that the LDS round trip hides behind the test instead of heading every
+  // trip.  After the last candidate of a word the read goes to slot base + 32 (ctz of an empty word taken as 32): always
+  // inside the staged image (it holds at least 3 records per sphere), and its result is dropped.
+#if !RT_MASK_PIPELINE
+#define RT_MASK_WORD(word_, base)                                                                  \
+  while (word_ != 0u) {                                                                            \
+    const uint32_t i = (base) + static_cast<uint32_t>(__builtin_ctz(word_));                       \
+    word_ &= word_ - 1u;                                                                           \
+    const float4 g = sph[i];                                                                       \
+    RT_MASK_TEST(g, i)                                                                             \
+  }
+#else
+#define RT_MASK_WORD(word_, base)                                                                  \
+  if (__builtin_amdgcn_ballot_w64(word_ != 0u) != 0ull) {                                          \
+    uint32_t ia = (base) + static_cast<uint32_t>(__builtin_ctzg(word_, 32)), ib;                   \
+    float4 ga = sph[ia], gb;                                                                       \
+    while (word_ != 0u) {                                                                          \
+      word_ &= word_ - 1u;                                                                         \
+      ib = (base) + static_cast<uint32_t>(__builtin_ctzg(word_, 32));                              \
+      gb = sph[ib];                                                                                \
+      RT_MASK_TEST(ga, ia)                                                                         \
+      if (word_ == 0u) break;                                                                      \
+      word_ &= word_ - 1u;                                                                         \
+      ia = (base) + static_cast<uint32_t>(__builtin_ctzg(word_, 32));                              \
+      ga = sph[ia];                                                                                \
+      RT_MASK_TEST(gb, ib)                                                                         \
+    }                                                                                              \
+  }
+#endif
+  RT_MASK_WORD(m0, 0u)
+  RT_MASK_WORD(m1, 32u)
+  if (WORDS32 > 2) {  // scenes of 65..128 spheres
+    RT_MASK_WORD(m2, 64u)
+    RT_MASK_WORD(m3, 96u)
   }
 #undef RT_MASK_WORD
+#undef RT_MASK_TEST
   return SphereHit{best_key, slot};
 }
 
@@ -613,6 +633,76 @@ __device__ __forceinline__ Hit finish_hit(const SceneView &sv, SphereHit sh, f3 
     }
   }
   return h;
+}
+
+// The plane part of ray.hlsl:97-107 on its own (ray.hlsl:69-94), and its merge with the sphere result: the same
+// lexicographic (distance, object index) minimum finish_hit builds, in another order — so that the planes can be tested
+// while the ray's candidate set is still on its way from memory (dirmask_lookup).
+__device__ __forceinline__ Hit nearest_plane(const SceneView &sv, f3 o, f3 d) {
+  Hit h;
+  h.t = 1000000.0f;  // ray.hlsl:98: the initial hit.distance
+  h.obj = -1;
+  h.slot = -1;
+  h.plane = false;
+  for (uint32_t j = 0; j < sv.n_pl; ++j) {
+    const float4 a = sv.pl_a[j], b = sv.pl_b[j];
+    const f3 c = mk3(a.x, a.y, a.z), nrm = mk3(b.x, b.y, b.z);
+    const int idx = static_cast<int>(f2u(b.w));
+    const float den = dot3(d, nrm);
+    if (fabsf(den) < kEpsilon) continue;
+    const float num = dot3(c - o, nrm);
+    const float t = num / den;
+    const f3 p = fma3(d, t, o);
+    const bool outside = (fabsf(p.x - c.x) > a.w) || (fabsf(p.y - c.y) > a.w) || (fabsf(p.z - c.z) > a.w);
+    const bool closer = (t < h.t) | ((t == h.t) & (idx < h.obj));
+    if (!outside & closer & (t >= kEpsilon)) {
+      h.t = t;
+      h.obj = idx;
+      h.slot = static_cast<int>(j);
+      h.plane = true;
+    }
+  }
+  return h;
+}
+__device__ __forceinline__ Hit merge_sphere_hit(const SceneView &sv, Hit h, SphereHit sh) {
+  if (sh.slot >= 0) {
+    const float t = __uint_as_float(sh.key + kEpsBits);
+    const int obj = sv.sph_obj[sh.slot];
+    // an equal distance only wins with the lower object index (planes and spheres share one index space)
+    if ((t < h.t) | ((t == h.t) & ((h.obj < 0) | (obj < h.obj)))) {
+      h.t = t;
+      h.obj = obj;
+      h.slot = sh.slot;
+      h.plane = false;
+    }
+  }
+  return h;
+}
+
+// ray_intersect (ray.hlsl:97-107) for the lanes of a wave whose rays the direction-mask table serves: the set is loaded
+// (every lane, no branch: lanes without a ray read the table's zero entry), the planes are tested while it is on its way,
+// then each lane tests its candidates.  One instance per entry width, so that the loaded registers go straight into the
+// loop (a merge of the two widths would force the wait for the load to the spot of the load).
+template <bool LEAN>
+__device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const FrameParams &fp, f3 o, f3 d, bool alive, uint32_t entry,
+                                                Hit miss) {
+  const DirMaskParams &dm = *sv.dm;
+  Hit hp = miss;
+  SphereHit sh;
+  if (dm.words == 1u) {  // wave-uniform
+    const uint2 w = *reinterpret_cast<const uint2 *>(dm.table + entry);
+    if (alive) hp = nearest_plane(sv, o, d);
+    sh = scan_spheres_masked<2>(sv.sph, o, d, w.x, w.y);
+  } else {
+    const uint4 w = *reinterpret_cast<const uint4 *>(dm.table + 2u * static_cast<size_t>(entry));
+    if (alive) hp = nearest_plane(sv, o, d);
+    sh = scan_spheres_masked<4>(sv.sph, o, d, w.x, w.y, w.z, w.w);
+  }
+  if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
+    const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
+    if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
+  }
+  return alive ? merge_sphere_hit(sv, hp, sh) : miss;
 }
 
 // State of one pixel's path between two iterations of frag.hlsl:36-43.
@@ -761,16 +851,17 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
     RT_REQUEST_X2
     if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     RT_PH_MARK(3)
-  } else if (uint32_t cand[4]; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, cand)) {
+  } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
     // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
-    const SphereHit sh = scan_spheres_masked(sv.sph, s.o, s.d, cand, sv.dm->words);
-    if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
-      const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
-      if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
-    }
+    Hit miss;
+    miss.t = 0.0f;
+    miss.obj = -1;
+    miss.slot = -1;
+    miss.plane = false;
+    const Hit h = intersect_masked<LEAN>(sv, fp, s.o, s.d, alive, entry, miss);
     RT_PH_MARK(1)
     RT_REQUEST_X2
-    if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+    if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, h, x1, x2, seed1);
     RT_PH_MARK(3)
   } else if (n_live <= 32u) {
     const SphereHit sh = scan_spheres_coop(sv.sph, sv.n_sph_pad, s.o, s.d, alive, live, n_live);
@@ -824,16 +915,10 @@ __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FramePa
       h = finish_hit(sv, sh, s.o, s.d);
     }
     RT_PH_MARK(0)
-  } else if (uint32_t cand[4]; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, cand)) {
-    // secondary rays of a small scene: every lane tests its own candidate set
-    const SphereHit sh = scan_spheres_masked(sv.sph, s.o, s.d, cand, sv.dm->words);
-    if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
-      const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
-      if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
-    }
+  } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
+    // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
+    h = intersect_masked<LEAN>(sv, fp, s.o, s.d, alive, entry, h);
     RT_PH_MARK(1)
-    if (alive) h = finish_hit(sv, sh, s.o, s.d);
-    RT_PH_MARK(3)
   } else if (n_live <= 32u) {
     const SphereHit sh = scan_spheres_coop(sv.sph, sv.n_sph_pad, s.o, s.d, alive, live, n_live);
     RT_PH_MARK(2)
@@ -1589,7 +1674,12 @@ __global__ void __launch_bounds__(256) dirmask_build_kernel(DirMaskParams dm, co
   if (threadIdx.x < n) s_reg[threadIdx.x] = reg[threadIdx.x];  // n <= 128 < 256 threads
   __syncthreads();
   const unsigned long long e = static_cast<unsigned long long>(blockIdx.x) * 256ull + threadIdx.x;
-  if (e >= entries) return;
+  if (e > entries) return;
+  if (e == entries) {  // the extra all-zero entry lanes without a ray read
+    table[e * dm.words] = 0ull;
+    if (dm.words > 1u) table[e * dm.words + 1u] = 0ull;
+    return;
+  }
   unsigned long long w[2];
   dirmask_entry(dm, static_cast<uint32_t>(e / dm.bins), static_cast<uint32_t>(e % dm.bins), s_reg, n, w);
   table[e * dm.words] = w[0];
@@ -1864,8 +1954,8 @@ int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned lon
 int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n, unsigned long long *table, hipStream_t stream) {
   const unsigned long long entries = static_cast<unsigned long long>(dm.nx) * dm.ny * dm.nz * dm.bins;
   if (entries == 0 || n == 0 || n > kDirMaskMaxSpheres) return static_cast<int>(hipErrorInvalidValue);
-  hipLaunchKernelGGL(dirmask_build_kernel, dim3(static_cast<uint32_t>((entries + 255ull) / 256ull)), dim3(256), 0, stream, dm, reg, n,
-                     table, entries);
+  hipLaunchKernelGGL(dirmask_build_kernel, dim3(static_cast<uint32_t>((entries + 256ull) / 256ull)), dim3(256), 0, stream, dm, reg, n,
+                     table, entries);  // entries + 1 threads: the last writes the zero entry
   return static_cast<int>(hipGetLastError());
 }
 

@@ -347,7 +347,7 @@ int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
       (void)hipFree(ctx->d_dirmask);
       ctx->d_dirmask = nullptr;
       ctx->dirmask_cap = 0;
-      RT_HIP(ctx, hipMalloc(&ctx->d_dirmask, entries * 2u * sizeof(unsigned long long)));  // room for two-word entries
+      RT_HIP(ctx, hipMalloc(&ctx->d_dirmask, (entries + 1u) * 2u * sizeof(unsigned long long)));  // two-word entries + the zero entry
       ctx->dirmask_cap = entries;
     }
     if (!ctx->d_dirmask_reg) RT_HIP(ctx, hipMalloc(&ctx->d_dirmask_reg, kDirMaskMaxSpheres * sizeof(float4)));
@@ -751,6 +751,7 @@ static DirMaskParams dirmask_from_info(const rt_dirmask_info *info) {
   dm.k = info->k;
   dm.bins = info->bins;
   dm.words = info->words;
+  dm.entries = info->nx * info->ny * info->nz * info->bins;
   dm.half_k = 0.5f * static_cast<float>(info->k);
   for (int a = 0; a < 3; ++a) {
     dm.bmin[a] = info->bmin[a];
