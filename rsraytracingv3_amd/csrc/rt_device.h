@@ -169,7 +169,7 @@ struct LaunchConfig {
 };
 int persistent_blocks_per_cu(size_t lds_bytes);
 // event-count build only (make events): counts since the last reset — see RT_CNT in rt_kernels.hip; zeros otherwise
-int prof_counts(unsigned long long out4[4], bool reset);
+int prof_counts(unsigned long long out8[8], bool reset);
 // The launch shape launch_render will use for this launch (the auto rule, and the fall-backs of a forced variant),
 // and what the streamed shape needs: records per queue shard for this launch's tiles, resident workgroups per CU.
 int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc);

@@ -48,9 +48,10 @@ namespace {
 #define RT_PERSISTENT_WAVES 6  // waves per SIMD the persistent kernel's register budget is held to
 #endif
 #ifndef RT_BLOCKS_WAVES_BATCH
-#define RT_BLOCKS_WAVES_BATCH 7   // waves per SIMD the re-packing shape is budgeted for in multi-frame launches: 72 VGPRs, no
-                                  // scratch since the instruction diet (A/B on one device: 6 waves / 80 VGPRs 37.7, 7 waves
-                                  // 38.1, 8 waves / 64 VGPRs + 28 B of scratch 35.8 Grays/s)
+#define RT_BLOCKS_WAVES_BATCH 6   // waves per SIMD the re-packing shape is budgeted for in multi-frame launches.  Round 2: 7 (72 VGPRs,
+                                  // no scratch: 6 / 7 / 8 waves 37.7 / 38.1 / 35.8 Grays/s).  With the balanced direction-mask scan
+                                  // the kernel needs 80 registers (at 72 it spills 4 VGPRs: 48.0 against 49.8 Grays/s at 6 waves;
+                                  // without the balanced scan 6 and 7 waves are level, 47.4 / 47.6)
 #endif
 #ifndef RT_BLOCKS_WAVES_SINGLE
 #define RT_BLOCKS_WAVES_SINGLE 5  // ... and in single-frame launches, several of which are in flight (register count held at the 5-wave step)
@@ -87,6 +88,21 @@ constexpr int kTile = 8;  // 8x8 pixels per tile / wave
 #define RT_XCHG_PATHS ((RT_BLOCK_NW - 1) * 64)  // re-packing needs the paths to fit one wave fewer
 #endif
 constexpr uint32_t kXchgPaths = RT_XCHG_PATHS;  // paths the block kernel's LDS exchange buffer holds
+#ifndef RT_BALANCED_SCAN
+#define RT_BALANCED_SCAN 1  // direction-mask scans of the re-packing shape: 1 = the wave's (ray, candidate) pairs are dealt evenly over
+                            // its lanes through LDS instead of every lane walking its own set (trips = the wave's heaviest lane)
+#endif
+// Per-wave LDS scratch of the balanced direction-mask scan: 64 rays (float4 + float2), 64 best hits (u64), kPairCap pairs (u16).
+constexpr uint32_t kPairCap = 512;
+constexpr uint32_t kScanScratchBytes = 64u * 16u + 64u * 8u + 64u * 8u + kPairCap * 2u;  // 3072
+constexpr uint32_t kXchgBytes = kXchgPaths * (RT_PACK_HITS ? 5u : 4u) * 16u;
+// With two waves per workgroup the scratch may share the exchange buffer's LDS: the buffer is only written after a count
+// barrier that both waves reach after their scans, and once it has been used a single wave is left.  Other workgroup sizes
+// keep the two apart.
+constexpr bool kScratchInXchg = RT_BLOCK_NW == 2;
+constexpr uint32_t kBlocksLdsExtra = !RT_BALANCED_SCAN ? kXchgBytes
+                                     : (kScratchInXchg ? (kXchgBytes > RT_BLOCK_NW * kScanScratchBytes ? kXchgBytes : RT_BLOCK_NW * kScanScratchBytes)
+                                                       : kXchgBytes + RT_BLOCK_NW * kScanScratchBytes);
 
 // Correctly rounded sqrt for x >= 2^-96 (also +0, +inf, NaN): v_sqrt_f32 is within 1 ulp, so
 // the IEEE result is one of {s-1ulp, s, s+1ulp}; the signs of the two fused residuals pick it
@@ -152,15 +168,26 @@ __device__ __forceinline__ float rcp_of_root(float s) {
 
 // Diagnostic build only (make events: -DRT_PROFILE_EVENTS; its atomics slow the kernel several times, so it is a build of
 // its own): event counts since the last rt_get_counter_words — [0] spheres tested by full scans (per wave), [1] of which
-// the wave took the root + closest-hit update, [2] sphere steps of cooperative scans, [3] spheres tested by listed scans.
+// the wave took the root + closest-hit update, [2] sphere steps of cooperative scans, [3] spheres tested by listed scans,
+// [4] direction-mask scans (per wave), [5] their loop trips (a trip = one sphere per lane still in the loop), [6] candidates
+// over all lanes, [7] rays (live lanes) of those scans.
 #ifdef RT_PROFILE_EVENTS
-__device__ unsigned long long g_prof_cnt[4];
+__device__ unsigned long long g_prof_cnt[8];
+// one count per wave from inside divergent code: the first lane that is active here adds it
+#define RT_CNT_ANY(k, n)                                                                                                   \
+  {                                                                                                                        \
+    if ((threadIdx.x & 63u) == static_cast<uint32_t>(__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))))                   \
+      atomicAdd(&g_prof_cnt[k], static_cast<unsigned long long>(n));                                                       \
+  }
+#define RT_CNT_LANE(k, n) atomicAdd(&g_prof_cnt[k], static_cast<unsigned long long>(n));
 #define RT_CNT(k, n)                                                                             \
   {                                                                                              \
     if ((threadIdx.x & 63u) == 0) atomicAdd(&g_prof_cnt[k], static_cast<unsigned long long>(n)); \
   }
 #else
 #define RT_CNT(k, n)
+#define RT_CNT_ANY(k, n)
+#define RT_CNT_LANE(k, n)
 #endif
 
 // The root of the sphere test, t = -dn - sqrt(q): sqrt_rn without its small-input branch.  For q >= 2^-96 (and +0)
@@ -479,6 +506,8 @@ __device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restric
                                                          uint32_t m2 = 0u, uint32_t m3 = 0u) {
   uint32_t best_key = kNoHitKey;
   int slot = -1;
+  RT_CNT(4, 1)
+  RT_CNT_LANE(6, __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3))
 #define RT_MASK_TEST(g, i)                                                                         \
   {                                                                                                \
     const float nx = o.x - g.x, ny = o.y - g.y, nz = o.z - g.z;                                    \
@@ -508,11 +537,13 @@ __device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restric
     uint32_t ia = (base) + static_cast<uint32_t>(__builtin_ctzg(word_, 32)), ib;                   \
     float4 ga = sph[ia], gb;                                                                       \
     while (word_ != 0u) {                                                                          \
+      RT_CNT_ANY(5, 1)                                                                             \
       word_ &= word_ - 1u;                                                                         \
       ib = (base) + static_cast<uint32_t>(__builtin_ctzg(word_, 32));                              \
       gb = sph[ib];                                                                                \
       RT_MASK_TEST(ga, ia)                                                                         \
       if (word_ == 0u) break;                                                                      \
+      RT_CNT_ANY(5, 1)                                                                             \
       word_ &= word_ - 1u;                                                                         \
       ia = (base) + static_cast<uint32_t>(__builtin_ctzg(word_, 32));                              \
       ga = sph[ia];                                                                                \
@@ -529,6 +560,91 @@ __device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restric
 #undef RT_MASK_WORD
 #undef RT_MASK_TEST
   return SphereHit{best_key, slot};
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave (DPP row shifts, then the two cross-row broadcasts of gfx9).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x111, 0xf, 0xf, true));  // row_shr:1
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x112, 0xf, 0xf, true));  // row_shr:2
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x114, 0xf, 0xf, true));  // row_shr:4
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x118, 0xf, 0xf, true));  // row_shr:8
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x142, 0xa, 0xf, true));  // row_bcast:15 -> rows 1, 3
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xc, 0xf, true));  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+// The same result as scan_spheres_masked for every lane, with the work dealt evenly: a lane's own walk costs the wave as
+// many trips as its heaviest lane has candidates (8.8 on the headline scene, where the mean is 2.9).  Here every lane
+// appends its (lane, slot) pairs to a list in LDS, the pairs are then tested 64 at a time by whichever lane they fall to
+// (the ray is read from LDS), and a pair that hits does an LDS atomic min of (key, slot) on the ray's slot — the
+// lexicographic minimum, which is what the strict '<' in ascending slot order selects.  Every lane of the wave must call it
+// (lanes without a ray pass empty words).  `scratch`: kScanScratchBytes of LDS owned by this wave.  Returns false
+// (wave-uniform) when the wave has more pairs than the list holds: the caller walks the sets lane by lane.
+template <int WORDS32>
+__device__ __forceinline__ bool scan_spheres_balanced(const float4 *__restrict__ sph, f3 o, f3 d, uint32_t m0, uint32_t m1, uint32_t m2,
+                                                      uint32_t m3, unsigned char *scratch, SphereHit &out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t p = static_cast<uint32_t>(__popc(m0) + __popc(m1));
+  if (WORDS32 > 2) p += static_cast<uint32_t>(__popc(m2) + __popc(m3));
+  const uint32_t incl = wave_inclusive_sum(p);
+  const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+  if (total > kPairCap) return false;
+  RT_CNT(4, 1)
+  RT_CNT(5, (total + 63u) >> 6)
+  RT_CNT_LANE(6, p)
+  out = SphereHit{kNoHitKey, -1};
+  if (total == 0u) return true;
+  float4 *rays_a = reinterpret_cast<float4 *>(scratch);
+  float2 *rays_b = reinterpret_cast<float2 *>(scratch + 64u * 16u);
+  unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 64u * 24u);
+  uint16_t *pairs = reinterpret_cast<uint16_t *>(scratch + 64u * 32u);
+  rays_a[lane] = make_float4(o.x, o.y, o.z, d.x);
+  rays_b[lane] = make_float2(d.y, d.z);
+  best[lane] = (static_cast<unsigned long long>(kNoHitKey) << 32) | 0xffffffffull;
+  uint32_t n = incl - p;
+  const uint32_t tag = lane << 7;
+#define RT_PAIR_WORD(word_, base)                                                                  \
+  while (word_ != 0u) {                                                                            \
+    pairs[n] = static_cast<uint16_t>(tag | ((base) + static_cast<uint32_t>(__builtin_ctz(word_)))); \
+    word_ &= word_ - 1u;                                                                           \
+    n += 1u;                                                                                       \
+  }
+  RT_PAIR_WORD(m0, 0u)
+  RT_PAIR_WORD(m1, 32u)
+  if (WORDS32 > 2) {
+    RT_PAIR_WORD(m2, 64u)
+    RT_PAIR_WORD(m3, 96u)
+  }
+#undef RT_PAIR_WORD
+  // LDS operations of one wave are carried out in the order they were issued; the fence only keeps the compiler from moving
+  // the reads below above the writes of other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (uint32_t first = 0u; first < total; first += 64u) {  // wave-uniform trip count
+    const uint32_t j = first + lane;
+    if (j < total) {
+      const uint32_t pr = pairs[j];
+      const uint32_t owner = pr >> 7, i = pr & 127u;
+      const float4 ra = rays_a[owner];
+      const float2 rb = rays_b[owner];
+      const float4 g = sph[i];
+      const float nx = ra.x - g.x, ny = ra.y - g.y, nz = ra.z - g.z;
+      const float dn = fmaf(rb.y, nz, fmaf(rb.x, ny, ra.w * nx));
+      const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
+      if (fminf(q, -dn) >= 0.0f) {
+        const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;
+        atomicMin(&best[owner], (static_cast<unsigned long long>(key) << 32) | i);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const unsigned long long res = best[lane];
+  out.key = static_cast<uint32_t>(res >> 32);
+  out.slot = static_cast<int>(static_cast<uint32_t>(res));  // 0xffffffff = -1: nothing hit
+  return true;
 }
 
 // ---- uniform grid walk (large scenes) -----------------------------------------------------------------------
@@ -685,18 +801,21 @@ __device__ __forceinline__ Hit merge_sphere_hit(const SceneView &sv, Hit h, Sphe
 // loop (a merge of the two widths would force the wait for the load to the spot of the load).
 template <bool LEAN>
 __device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const FrameParams &fp, f3 o, f3 d, bool alive, uint32_t entry,
-                                                Hit miss) {
+                                                Hit miss, unsigned char *scratch = nullptr) {
   const DirMaskParams &dm = *sv.dm;
   Hit hp = miss;
   SphereHit sh;
+  RT_CNT(7, __popcll(__builtin_amdgcn_ballot_w64(alive)))
   if (dm.words == 1u) {  // wave-uniform
     const uint2 w = *reinterpret_cast<const uint2 *>(dm.table + entry);
     if (alive) hp = nearest_plane(sv, o, d);
-    sh = scan_spheres_masked<2>(sv.sph, o, d, w.x, w.y);
+    if (!(RT_BALANCED_SCAN && scratch != nullptr && scan_spheres_balanced<2>(sv.sph, o, d, w.x, w.y, 0u, 0u, scratch, sh)))
+      sh = scan_spheres_masked<2>(sv.sph, o, d, w.x, w.y);
   } else {
     const uint4 w = *reinterpret_cast<const uint4 *>(dm.table + 2u * static_cast<size_t>(entry));
     if (alive) hp = nearest_plane(sv, o, d);
-    sh = scan_spheres_masked<4>(sv.sph, o, d, w.x, w.y, w.z, w.w);
+    if (!(RT_BALANCED_SCAN && scratch != nullptr && scan_spheres_balanced<4>(sv.sph, o, d, w.x, w.y, w.z, w.w, scratch, sh)))
+      sh = scan_spheres_masked<4>(sv.sph, o, d, w.x, w.y, w.z, w.w);
   }
   if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
     const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
@@ -896,7 +1015,7 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
 template <bool LEAN>
 __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FrameParams &fp, const Path &s, bool alive,
                                               const unsigned long long *__restrict__ primary_mask,
-                                              const unsigned long long *__restrict__ primary_mask2 RT_PH_PARAMS) {
+                                              const unsigned long long *__restrict__ primary_mask2, unsigned char *scratch RT_PH_PARAMS) {
   Hit h;
   h.t = 0.0f;
   h.obj = -1;
@@ -917,7 +1036,7 @@ __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FramePa
     RT_PH_MARK(0)
   } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
     // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
-    h = intersect_masked<LEAN>(sv, fp, s.o, s.d, alive, entry, h);
+    h = intersect_masked<LEAN>(sv, fp, s.o, s.d, alive, entry, h, scratch);
     RT_PH_MARK(1)
   } else if (n_live <= 32u) {
     const SphereHit sh = scan_spheres_coop(sv.sph, sv.n_sph_pad, s.o, s.d, alive, live, n_live);
@@ -1109,6 +1228,9 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   // do not pack and therefore have no second barrier.
   __shared__ unsigned int wave_count[2][NW];
   float4 *xchg = lds_all + sc.image_records;  // kXchgPaths paths x 4 float4, behind the staged scene image
+  // this wave's scratch for the balanced direction-mask scan (shares the exchange buffer's LDS when NW == 2: kScratchInXchg)
+  unsigned char *scratch = reinterpret_cast<unsigned char *>(xchg) + (kScratchInXchg ? 0u : kXchgBytes) +
+                           (threadIdx.x >> 6) * kScanScratchBytes;
   for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
   const SceneView sv = make_view(sc, lds_all, lds_all);
   const uint32_t lane = threadIdx.x & 63u;
@@ -1147,7 +1269,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   // waves when they fit -> shade.  Packing between the scan and the shading (instead of after the shading) spares the
   // surplus wave its shading pass: the misses, a third of the rays of a bounce, have left by then.
   for (;;) {
-    Hit h = path_scan_wave<LEAN>(sv, fp, s, alive, primary_mask, primary_mask2 RT_PH_ARGS);
+    Hit h = path_scan_wave<LEAN>(sv, fp, s, alive, primary_mask, primary_mask2, scratch RT_PH_ARGS);
     primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
     if (alive && h.obj < 0) {  // frag.hlsl:14-17: a miss ends the path (its skybox texel is fetched in path_end)
       (void)path_shade<RT_DEFER_SKY_BLOCKS, LEAN>(sv, fp, s, h, 0.0f, 0.0f, 0.0f);
@@ -1895,7 +2017,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
                        fp, static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 3) {
     const dim3 blocks((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW, tiles_y, fp.batch);  // x: tile columns, y: tile rows, z: frames
-    const size_t bytes = lds_image + static_cast<size_t>(kXchgPaths) * (RT_PACK_HITS ? 5 : 4) * sizeof(float4);
+    const size_t bytes = lds_image + kBlocksLdsExtra;  // exchange buffer and the waves' scan scratch
     const bool lean = sample_only(fp);
     if (fp.batch > 1u && lean) {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
@@ -1967,16 +2089,16 @@ int stream_blocks_per_cu(size_t lds_bytes) {
   return n;
 }
 
-int prof_counts(unsigned long long out4[4], bool reset) {
+int prof_counts(unsigned long long out8[8], bool reset) {
 #ifdef RT_PROFILE_EVENTS
-  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_prof_cnt), 4 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_prof_cnt), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
   if (reset) {
-    const unsigned long long zero[4] = {0, 0, 0, 0};
+    const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof_cnt), zero, sizeof zero) != hipSuccess) return 1;
   }
   return 0;
 #else
-  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
   return 0;
 #endif
 }

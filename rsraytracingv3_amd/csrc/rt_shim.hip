@@ -1585,9 +1585,13 @@ int rt_get_counter_words(rt_context *ctx, uint64_t *out16) {
     out16[w] = 0;
     for (uint32_t sh = 0; sh < kTotalShards; ++sh) out16[w] += line[sh * kTotalShardStride + w];
   }
-  unsigned long long events[4];  // profiling build: event counts since the previous call (words 12..15)
-  if (prof_counts(events, true) == 0)
+  unsigned long long events[8];  // event-count build: counts since the previous call — words 12..15, and the direction-mask
+                                 // counts in words 4..7 (the phase sums, which that build does not fill)
+  if (prof_counts(events, true) == 0) {
     for (int k = 0; k < 4; ++k) out16[12 + k] = events[k];
+    if (events[4] != 0)
+      for (int k = 0; k < 4; ++k) out16[4 + k] = events[4 + k];
+  }
   return RT_OK;
 }
 

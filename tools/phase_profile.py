@@ -65,6 +65,11 @@ print("variant %d, %d frame(s) per launch, kernel %.3f ms, %d segments, %d wave 
 for name, v in zip(NAMES, ph):
     print("  %-42s %6.2f %%   %.3e wave-cycles" % (name, 100.0 * v / ph.sum(), v))
 ev = [int(w) for w in words[12:16]]
+if any(ev) and "events" in os.environ.get("RT355_LIB", ""):  # event-count build: words 4..7 are the direction-mask counts
+    dmc = [int(w) for w in words[4:8]]
+    if dmc[0]:
+        print("  direction-mask scans of that launch: %d wave-scans, %.2f loop trips each, %.1f rays each, %.2f candidates per ray"
+              % (dmc[0], dmc[1] / dmc[0], dmc[3] / dmc[0], dmc[2] / max(dmc[3], 1)))
 if any(ev):
     print("  events of that launch: full scans tested %d spheres per wave-scan total, root + update taken for %d of them "
           "(%.1f %%); cooperative scans %d sphere steps; listed (primary) scans %d spheres"
