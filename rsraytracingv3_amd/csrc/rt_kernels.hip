@@ -805,7 +805,10 @@ __device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const Frame
   const DirMaskParams &dm = *sv.dm;
   Hit hp = miss;
   SphereHit sh;
-  RT_CNT(7, __popcll(__builtin_amdgcn_ballot_w64(alive)))
+#ifdef RT_PROFILE_EVENTS
+  const int n_rays_ = __popcll(__builtin_amdgcn_ballot_w64(alive));  // every lane takes part in the ballot; lane 0 adds the count
+  RT_CNT(7, n_rays_)
+#endif
   if (dm.words == 1u) {  // wave-uniform
     const uint2 w = *reinterpret_cast<const uint2 *>(dm.table + entry);
     if (alive) hp = nearest_plane(sv, o, d);
@@ -1967,7 +1970,11 @@ int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfi
     // scenes with hundreds of spheres (grid or not) and small single frames are fastest as plain tiles.  The
     // resident-wave shape (2) is never the fastest since the primary-ray culling, which it cannot use; selectable.
     // The streamed shape (4) only draws level from 16 frames per launch up; selectable.
-    const uint64_t enough = fp.batch > 1u ? 20000ull : 24000ull;  // single frames: a whole 1080p frame (32 400 tiles) re-packs, half of one renders as tiles
+    // single frames: without a direction-mask table a whole 1080p frame (32 400 tiles) re-packs, half of one renders as tiles;
+    // with the table (whose balanced scan only the re-packing shape has) it wins down to a rank's eighth of a 1080p frame
+    // (tools/variant_sweep.py, ms per frame tiles / re-packing: 1080p N = 2: 0.0737 / 0.0667, N = 4: 0.0420 / 0.0400, N = 8:
+    // 0.0312 / 0.0309; 4K N = 8: 0.0683 / 0.0640)
+    const uint64_t enough = fp.batch > 1u ? 20000ull : (sc.dm.enabled ? 4000ull : 24000ull);
     variant = (sc.n_sph_pad > 136u || tiles < enough || sc.grid.enabled) ? 0 : 3;  // up to 128 spheres (+ 8 padding records)
 #if RT_STREAM_MIN_TILES
     if (variant == 3 && tiles >= RT_STREAM_MIN_TILES && sample_only(fp)) variant = 4;

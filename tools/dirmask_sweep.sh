@@ -8,6 +8,7 @@ run --dirmask 1
 run --dirmask 0
 run --dirmask 1
 run --dirmask 1 --dirmask-k 8
+run --dirmask 1 --dirmask-k 12 --dirmask-cells 16384
 run --dirmask 1 --dirmask-k 10
 run --dirmask 1 --dirmask-k 16
 for n in 12 16 20 24 28 32 40 48; do run --dirmask 1 --spheres $n; run --dirmask 0 --spheres $n; done
@@ -18,9 +19,3 @@ run --dirmask 1 --batch 1
 run --dirmask 0 --batch 1
 run --dirmask 1 --width 3840 --height 2160
 run --dirmask 0 --width 3840 --height 2160
-run --spheres 128
-run --spheres 128 --grid-min 1
-run --spheres 96
-run --variant 4
-run --variant 4 --batch 16
-run --batch 16
