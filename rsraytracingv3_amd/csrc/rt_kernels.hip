@@ -470,15 +470,20 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
 // branch around the load.  Returns false — wave-uniform — when some live lane's ray is not served by the table (origin
 // outside the near box, direction not a unit vector, NaN): the wave then scans linearly as before.
 __device__ __forceinline__ bool dirmask_lookup(const DirMaskParams &dm, f3 o, f3 d, bool alive, uint32_t &entry) {
-  const bool served = (fabsf(dot3(d, d) - 1.0f) <= 4e-6f) & (o.x >= dm.near_min[0]) & (o.x <= dm.near_max[0]) &
-                      (o.y >= dm.near_min[1]) & (o.y <= dm.near_max[1]) & (o.z >= dm.near_min[2]) & (o.z <= dm.near_max[2]);
-  if (__builtin_amdgcn_ballot_w64(alive & !served) != 0ull) return false;
+  // unit direction (also false for a NaN anywhere in d); the origin's boxes are tested inner one first: a wave whose rays all
+  // start inside the spheres' box — nearly every wave — needs neither the near-box test nor the entry point
+  const bool unit = fabsf(dot3(d, d) - 1.0f) <= 4e-6f;
+  const bool inside = (o.x >= dm.bmin[0]) & (o.x <= dm.bmax[0]) & (o.y >= dm.bmin[1]) & (o.y <= dm.bmax[1]) & (o.z >= dm.bmin[2]) &
+                      (o.z <= dm.bmax[2]);  // false for a NaN in o
+  if (__builtin_amdgcn_ballot_w64(alive & !unit) != 0ull) return false;
   f3 p = o;
   bool reaches = true;
-  const bool outside = !((o.x >= dm.bmin[0]) & (o.x <= dm.bmax[0]) & (o.y >= dm.bmin[1]) & (o.y <= dm.bmax[1]) &
-                         (o.z >= dm.bmin[2]) & (o.z <= dm.bmax[2]));
-  if (__builtin_amdgcn_ballot_w64(alive & outside) != 0ull) {
+  if (__builtin_amdgcn_ballot_w64(alive & !inside) != 0ull) {
+    const bool near = (o.x >= dm.near_min[0]) & (o.x <= dm.near_max[0]) & (o.y >= dm.near_min[1]) & (o.y <= dm.near_max[1]) &
+                      (o.z >= dm.near_min[2]) & (o.z <= dm.near_max[2]);  // the spheres' box lies inside the near box
+    if (__builtin_amdgcn_ballot_w64(alive & !near) != 0ull) return false;
     // rays that start outside the box continue from the point where they enter it; a ray that misses it meets no sphere
+    const bool outside = !inside;
     const float big = 1e30f;
     const float ivx = fabsf(d.x) > 1e-30f ? __builtin_amdgcn_rcpf(d.x) : (d.x < 0.0f ? -big : big);
     const float ivy = fabsf(d.y) > 1e-30f ? __builtin_amdgcn_rcpf(d.y) : (d.y < 0.0f ? -big : big);

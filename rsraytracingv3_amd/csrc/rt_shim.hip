@@ -128,7 +128,7 @@ struct rt_context {
   int dirmask_cells = 4096;      // RT_OPT_DIRMASK_CELLS: cells aimed at
   int dirmask_k = 12;            // RT_OPT_DIRMASK_K: bins per cube-map face edge
   unsigned long long *d_dirmask = nullptr;
-  size_t dirmask_cap = 0;        // in entries
+  size_t dirmask_cap = 0;        // in 64-bit words
   float4 *d_dirmask_reg = nullptr;
   std::vector<float4> dirmask_built_for;  // sphere records (+ one record of options) the table on the device was built from
   int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid; up to 128 spheres the
@@ -343,12 +343,17 @@ int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
                     std::memcmp(key.data(), ctx->dirmask_built_for.data(), key.size() * sizeof(float4)) == 0;
   if (!same) {
     ctx->dirmask_built_for.clear();
-    if (ctx->dirmask_cap < entries) {
+    const size_t need_words = (entries + 1u) * dm.words;  // + the all-zero entry
+    if (ctx->dirmask_cap < need_words) {
       (void)hipFree(ctx->d_dirmask);
       ctx->d_dirmask = nullptr;
       ctx->dirmask_cap = 0;
-      RT_HIP(ctx, hipMalloc(&ctx->d_dirmask, (entries + 1u) * 2u * sizeof(unsigned long long)));  // two-word entries + the zero entry
-      ctx->dirmask_cap = entries;
+      if (hipMalloc(&ctx->d_dirmask, need_words * sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();  // no room for the table: the scene renders without one (linear scans), it does not fail
+        ctx->d_dirmask = nullptr;
+        return RT_OK;
+      }
+      ctx->dirmask_cap = need_words;
     }
     if (!ctx->d_dirmask_reg) RT_HIP(ctx, hipMalloc(&ctx->d_dirmask_reg, kDirMaskMaxSpheres * sizeof(float4)));
     RT_HIP(ctx, hipMemcpy(ctx->d_dirmask_reg, reg, n * sizeof(float4), hipMemcpyHostToDevice));
