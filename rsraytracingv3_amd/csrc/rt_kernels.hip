@@ -48,10 +48,14 @@ namespace {
 #define RT_PERSISTENT_WAVES 6  // waves per SIMD the persistent kernel's register budget is held to
 #endif
 #ifndef RT_BLOCKS_WAVES_BATCH
-#define RT_BLOCKS_WAVES_BATCH 6   // waves per SIMD the re-packing shape is budgeted for in multi-frame launches.  Round 2: 7 (72 VGPRs,
-                                  // no scratch: 6 / 7 / 8 waves 37.7 / 38.1 / 35.8 Grays/s).  With the balanced direction-mask scan
-                                  // the kernel needs 80 registers (at 72 it spills 4 VGPRs: 48.0 against 49.8 Grays/s at 6 waves;
-                                  // without the balanced scan 6 and 7 waves are level, 47.4 / 47.6)
+#define RT_BLOCKS_WAVES_BATCH 7   // waves per SIMD the re-packing shape is budgeted for in multi-frame launches: 72 VGPRs, no scratch
+                                  // (round 2, A/B on one device: 6 / 7 / 8 waves 37.7 / 38.1 / 35.8 Grays/s; round 3, with the balanced
+                                  // direction-mask scan: 5 / 6 / 7 / 8 waves 45.4 / 49.3 / 50.2 / 47.2 — at 7 it only fits since the
+                                  // scan recomputes its lane-derived LDS addresses instead of keeping them across the bounce loop)
+#endif
+#ifndef RT_BLOCKS_WAVES_BATCH_WIDE
+#define RT_BLOCKS_WAVES_BATCH_WIDE 6  // ... for scenes whose direction-mask sets take two words (65..128 spheres, the reference's 80
+                                      // slots): 6 / 7 waves 44.4 / 43.6 Grays/s
 #endif
 #ifndef RT_BLOCKS_WAVES_SINGLE
 #define RT_BLOCKS_WAVES_SINGLE 5  // ... and in single-frame launches, several of which are in flight (register count held at the 5-wave step)
@@ -77,6 +81,9 @@ constexpr int kTile = 8;  // 8x8 pixels per tile / wave
                        // frame per launch in Grays/s: 4 waves 31.8 / 32.0, 2 waves 33.4 / 30.8 at 6 waves per SIMD and
                        // 32.5 / 33.1 at 5, 1 wave 32.7 / 30.5, 8 waves 27.0 / 27.5 — hence 2 waves, and the register
                        // budget by launch kind
+#endif
+#ifndef RT_PLANES_AFTER_SCAN
+#define RT_PLANES_AFTER_SCAN 0
 #endif
 #ifndef RT_MASK_PIPELINE
 #define RT_MASK_PIPELINE 1  // direction-mask scans: request the next candidate's record before the current one is tested
@@ -583,12 +590,18 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
 // appends its (lane, slot) pairs to a list in LDS, the pairs are then tested 64 at a time by whichever lane they fall to
 // (the ray is read from LDS), and a pair that hits does an LDS atomic min of (key, slot) on the ray's slot — the
 // lexicographic minimum, which is what the strict '<' in ascending slot order selects.  Every lane of the wave must call it
-// (lanes without a ray pass empty words).  `scratch`: kScanScratchBytes of LDS owned by this wave.  Returns false
+// (lanes without a ray pass empty words).  `scratch_base`: the workgroup's scan scratch, kScanScratchBytes per wave.  Returns false
 // (wave-uniform) when the wave has more pairs than the list holds: the caller walks the sets lane by lane.
 template <int WORDS32>
 __device__ __forceinline__ bool scan_spheres_balanced(const float4 *__restrict__ sph, f3 o, f3 d, uint32_t m0, uint32_t m1, uint32_t m2,
-                                                      uint32_t m3, unsigned char *scratch, SphereHit &out) {
-  const uint32_t lane = threadIdx.x & 63u;
+                                                      uint32_t m3, unsigned char *scratch_base, SphereHit &out) {
+  // the thread index goes through an opaque move: everything derived from it (lane, the wave's scratch, the LDS addresses) is
+  // then recomputed here, a few instructions per scan, instead of being kept in registers across the whole bounce loop —
+  // at 72 registers the compiler otherwise spills exactly those values and reloads them from scratch memory in every scan
+  uint32_t tid = threadIdx.x;
+  asm volatile("; thread index re-read per scan" : "+v"(tid));
+  const uint32_t lane = tid & 63u;
+  unsigned char *scratch = scratch_base + (tid >> 6) * kScanScratchBytes;
   uint32_t p = static_cast<uint32_t>(__popc(m0) + __popc(m1));
   if (WORDS32 > 2) p += static_cast<uint32_t>(__popc(m2) + __popc(m3));
   const uint32_t incl = wave_inclusive_sum(p);
@@ -814,17 +827,21 @@ __device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const Frame
   const int n_rays_ = __popcll(__builtin_amdgcn_ballot_w64(alive));  // every lane takes part in the ballot; lane 0 adds the count
   RT_CNT(7, n_rays_)
 #endif
+  // RT_PLANES_AFTER_SCAN: the planes are tested after the balanced scan instead of under the table load's latency — four
+  // registers fewer are live through the scan, which is what lets the multi-frame kernel keep 7 waves per SIMD
+  const bool planes_late = RT_PLANES_AFTER_SCAN && RT_BALANCED_SCAN && scratch != nullptr;
   if (dm.words == 1u) {  // wave-uniform
     const uint2 w = *reinterpret_cast<const uint2 *>(dm.table + entry);
-    if (alive) hp = nearest_plane(sv, o, d);
+    if (!planes_late && alive) hp = nearest_plane(sv, o, d);
     if (!(RT_BALANCED_SCAN && scratch != nullptr && scan_spheres_balanced<2>(sv.sph, o, d, w.x, w.y, 0u, 0u, scratch, sh)))
       sh = scan_spheres_masked<2>(sv.sph, o, d, w.x, w.y);
   } else {
     const uint4 w = *reinterpret_cast<const uint4 *>(dm.table + 2u * static_cast<size_t>(entry));
-    if (alive) hp = nearest_plane(sv, o, d);
+    if (!planes_late && alive) hp = nearest_plane(sv, o, d);
     if (!(RT_BALANCED_SCAN && scratch != nullptr && scan_spheres_balanced<4>(sv.sph, o, d, w.x, w.y, w.z, w.w, scratch, sh)))
       sh = scan_spheres_masked<4>(sv.sph, o, d, w.x, w.y, w.z, w.w);
   }
+  if (planes_late && alive) hp = nearest_plane(sv, o, d);
   if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
     const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
     if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
@@ -1236,9 +1253,9 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   // do not pack and therefore have no second barrier.
   __shared__ unsigned int wave_count[2][NW];
   float4 *xchg = lds_all + sc.image_records;  // kXchgPaths paths x 4 float4, behind the staged scene image
-  // this wave's scratch for the balanced direction-mask scan (shares the exchange buffer's LDS when NW == 2: kScratchInXchg)
-  unsigned char *scratch = reinterpret_cast<unsigned char *>(xchg) + (kScratchInXchg ? 0u : kXchgBytes) +
-                           (threadIdx.x >> 6) * kScanScratchBytes;
+  // the waves' scratch for the balanced direction-mask scan (shares the exchange buffer's LDS when NW == 2: kScratchInXchg);
+  // wave w's part starts w * kScanScratchBytes in
+  unsigned char *scratch = reinterpret_cast<unsigned char *>(xchg) + (kScratchInXchg ? 0u : kXchgBytes);
   for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
   const SceneView sv = make_view(sc, lds_all, lds_all);
   const uint32_t lane = threadIdx.x & 63u;
@@ -2032,8 +2049,13 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     const size_t bytes = lds_image + kBlocksLdsExtra;  // exchange buffer and the waves' scan scratch
     const bool lean = sample_only(fp);
     if (fp.batch > 1u && lean) {
-      if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
-      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      if (sc.dm.enabled && sc.dm.words > 1u) {
+        if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH_WIDE;
+        hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH_WIDE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      } else {
+        if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
+        hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      }
     } else if (lean) {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
       hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
