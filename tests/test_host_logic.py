@@ -154,13 +154,14 @@ def test_trace_union_counts_shared_device_time_once(tmp_path):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The JSON line bench.py printed on the GPU box (profiles/r02_bench_driver_flags.json, the driver's flags): every key
-    the bench contract names is there, with the types and relations it asks for."""
+    """The JSON line bench.py printed on the GPU box (profiles/r03_bench_driver_flags.json, the driver's flags): every key
+    the bench contract names is there, with the types and relations it asks for; the counters it imports from a committed
+    PMC profile name their source."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r02_bench_driver_flags.json")) as f:
-        d = json.loads(f.read())
+    with open(os.path.join(root, "profiles", "r03_bench_driver_flags.json")) as f:
+        d = json.loads([line for line in f if line.startswith("{")][-1])
     for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                       ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
                       ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
@@ -177,3 +178,22 @@ def test_committed_bench_line_keeps_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
     assert 0.0 < d["valu"]["frac"] < 1.0 and d["valu"]["peak"] == 157.3
+    # imported, not measured in the run: says so, and from which kernel sources
+    src = r["traffic_source"]
+    assert src["file"].startswith("profiles/traffic_r") and src["used"] is True and len(src["kernel_source_sha256"]) == 16
+    assert "algorithmic" in r["achieved_basis"] and abs(r["measured_gbs"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+    for leg in ("one_frame_per_launch", "reference_80_slots"):
+        assert d["config"][leg]["mrays_per_s"] > 0
+
+
+def test_profile_counters_are_only_quoted_for_the_sources_they_were_measured_on():
+    """profiles/traffic_r03.json records the sha256 of the kernel sources it was collected on; bench.py quotes it only when
+    the tree still has those sources.  The committed profile must belong to the committed sources."""
+    import json
+    import os
+    from rsraytracingv3_amd import _native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "traffic_r03.json")) as f:
+        prof = json.load(f)
+    assert prof["kernel_source_sha256"] == _native.kernel_source_hash(), \
+        "csrc/ or include/ changed since the PMC profile was collected: re-run tools/profile_round.sh (bench.py now reports traffic null)"
