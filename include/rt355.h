@@ -183,6 +183,39 @@ RT355_API int rt_comm_abort(rt_context *ctx);
  * communicator only on rank 0 (other ranks: RT_ERR_INVALID_ARGUMENT; their rt_read_rgba8 still returns their rows). */
 RT355_API int rt_read_frame_rgba8(rt_context *ctx, void *dst, size_t bytes);
 
+/* The same multi-GPU frame driven by ONE process — the reference's shape: one process, one loop (src/app.rs:64-104 binds
+ * the adapter, :208-254 renders).  rt_multi_create binds n devices (`Initial::gpu_setup` once per device) and gives device i
+ * the row strips s with s % n == i; every rt_multi_set_* forwards to all devices (scene, skybox and random texture are
+ * replicated), every rt_multi_render* launches on all of them — the launches are asynchronous, the devices work side by
+ * side — and then gathers on device_ids[0]: peer copies of the other devices' strips (hipMemcpyPeerAsync, one xGMI link per
+ * peer, no ring) into the layout rank 0 of a communicator receives, then the same assembly kernel; targets alternate, so
+ * the gather of launch k runs beside launch k + 1.  rt_multi_read_frame_rgba8 returns the assembled height x width frame,
+ * bit-identical to the single-GPU frame.  device_ids may name one device several times (what the tests do on one GPU).
+ * rt_multi_context(m, i) is device i's context for per-device calls (rt_get_stats, rt_set_option, rt_last_error); do not
+ * render, resize or destroy through it.  No RCCL involved; use rt_comm_init when the ranks are separate processes. */
+typedef struct rt_multi rt_multi;
+RT355_API int rt_multi_create(const int *device_ids, uint32_t n_devices, uint32_t strip_rows, rt_multi **out);
+RT355_API int rt_multi_destroy(rt_multi *m);
+RT355_API uint32_t rt_multi_device_count(rt_multi *m);
+RT355_API rt_context *rt_multi_context(rt_multi *m, uint32_t index);
+RT355_API const char *rt_multi_last_error(rt_multi *m);
+RT355_API int rt_multi_set_skybox(rt_multi *m, uint32_t width, uint32_t height, const float *rgba32f);
+RT355_API int rt_multi_set_skybox_exr(rt_multi *m, const char *path);
+RT355_API int rt_multi_set_random(rt_multi *m, uint32_t width, uint32_t height, const float *r32f);
+RT355_API int rt_multi_generate_random(rt_multi *m, uint32_t width, uint32_t height, uint64_t seed);
+RT355_API int rt_multi_set_scene(rt_multi *m, const void *objects, uint32_t object_count, const void *lights, uint32_t light_count,
+                                 const void *config112);
+RT355_API int rt_multi_resize(rt_multi *m, uint32_t width, uint32_t height);
+RT355_API int rt_multi_set_accum_mode(rt_multi *m, int mode);
+RT355_API int rt_multi_set_option(rt_multi *m, int option, int value);
+RT355_API int rt_multi_render(rt_multi *m, float jitter_x, float jitter_y, uint32_t progressive_count);
+RT355_API int rt_multi_render_frame(rt_multi *m, const void *framedata16);
+RT355_API int rt_multi_render_frames(rt_multi *m, uint32_t n_frames, const void *framedata16);
+RT355_API int rt_multi_sync(rt_multi *m);
+RT355_API int rt_multi_read_frame_rgba8(rt_multi *m, void *dst, size_t bytes);
+/* Sums over the devices (segments, rough hits, pixels, local rows, wave iterations); last_kernel_ms = the slowest device's. */
+RT355_API int rt_multi_get_stats(rt_multi *m, rt_stats *out);
+
 /* Rank 0's assembly step on its own, for hosts that move the strips by another transport (and for testing the
  * layout without a second GPU): rank0_rows = rank 0's local rows, peer_rows = the local rows of ranks 1 .. world-1
  * concatenated in rank order (exactly what rank 0 receives), all host pointers to sRGB8 texels; frame gets the

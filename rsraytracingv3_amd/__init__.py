@@ -5,7 +5,7 @@ the C-ABI of ``include/rt355.h``; this package is its host-side mirror of the re
 native library; using ``Device`` does, and fails loudly if it is not built."""
 from .bytes import bytes_concat, bytes_concat_owned  # noqa: F401
 from .scene import Camera, Geometry, Light, Material, Object, Scene  # noqa: F401
-from .connection import Connection, Device, FrameData, RandomTexture, RenderTarget, render_scene  # noqa: F401
+from .connection import Connection, Device, FrameData, MultiDevice, RandomTexture, RenderTarget, render_scene  # noqa: F401
 
-__all__ = ["Camera", "Geometry", "Light", "Material", "Object", "Scene", "Connection", "Device", "FrameData",
+__all__ = ["Camera", "Geometry", "Light", "Material", "Object", "Scene", "Connection", "Device", "MultiDevice", "FrameData",
            "RandomTexture", "RenderTarget", "render_scene", "bytes_concat", "bytes_concat_owned"]

@@ -84,6 +84,25 @@ SIGNATURES = {
     "rt_comm_idle": (_i, [_vp, _vp]),
     "rt_comm_abort": (_i, [_vp]),
     "rt_read_frame_rgba8": (_i, [_vp, _vp, _sz]),
+    "rt_multi_create": (_i, [C.POINTER(C.c_int), _u32, _u32, C.POINTER(_vp)]),
+    "rt_multi_destroy": (_i, [_vp]),
+    "rt_multi_device_count": (_u32, [_vp]),
+    "rt_multi_context": (_vp, [_vp, _u32]),
+    "rt_multi_last_error": (C.c_char_p, [_vp]),
+    "rt_multi_set_skybox": (_i, [_vp, _u32, _u32, _vp]),
+    "rt_multi_set_skybox_exr": (_i, [_vp, C.c_char_p]),
+    "rt_multi_set_random": (_i, [_vp, _u32, _u32, _vp]),
+    "rt_multi_generate_random": (_i, [_vp, _u32, _u32, C.c_uint64]),
+    "rt_multi_set_scene": (_i, [_vp, _vp, _u32, _vp, _u32, _vp]),
+    "rt_multi_resize": (_i, [_vp, _u32, _u32]),
+    "rt_multi_set_accum_mode": (_i, [_vp, _i]),
+    "rt_multi_set_option": (_i, [_vp, _i, _i]),
+    "rt_multi_render": (_i, [_vp, _f, _f, _u32]),
+    "rt_multi_render_frame": (_i, [_vp, _vp]),
+    "rt_multi_render_frames": (_i, [_vp, C.c_uint32, _vp]),
+    "rt_multi_sync": (_i, [_vp]),
+    "rt_multi_read_frame_rgba8": (_i, [_vp, _vp, _sz]),
+    "rt_multi_get_stats": (_i, [_vp, C.POINTER(RtStats)]),
     "rt_assemble_strips": (_i, [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rt_set_accum_mode": (_i, [_vp, _i]),
     "rt_set_outputs": (_i, [_vp, _u32]),
@@ -120,16 +139,14 @@ _lib = None
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the sources librt355.so is built from (csrc/*.hip, *.h, *.cpp, Makefile; include/*.h), in name
-    order.  Profiles record it (tools/pmc_summary.py) and bench.py only quotes a profile's counters when the tree it
-    runs from still has the sources the profile was measured on."""
-    import glob
+    """sha256 over the sources that decide what the render kernels do and how they are launched (csrc/rt_kernels.hip,
+    rt_shim.hip, rt_device.h, rt_math.h, rt_dirmask.h, rt_grid.h, Makefile), in name order.  Profiles record it
+    (tools/pmc_summary.py) and bench.py only quotes a profile's counters when the tree it runs from still has the sources
+    the profile was measured on."""
     import hashlib
     h = hashlib.sha256()
-    root = os.path.dirname(_HERE)
-    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
-                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "csrc", "Makefile")] +
-                   glob.glob(os.path.join(root, "include", "*.h")))
+    names = ("Makefile", "rt_device.h", "rt_dirmask.h", "rt_grid.h", "rt_kernels.hip", "rt_math.h", "rt_shim.hip")
+    files = [os.path.join(_HERE, "csrc", n) for n in names]
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         with open(f, "rb") as fh:

@@ -141,6 +141,73 @@ class Device:
         return b
 
 
+class _MultiLib:
+    """``rt_x(handle, ...)`` -> ``rt_multi_x(handle, ...)``, so that Connection / RenderTarget / RandomTexture drive an
+    ``rt_multi`` with the calls they make on one device.  ``rt_read_rgba8`` is the assembled frame (all rows are local to
+    the rt_multi as a whole); calls without a multi-device form raise."""
+    _NO_HANDLE = ("rt_exr_last_error", "rt_exr_read_rgba32f", "rt_exr_free", "rt_abi_version")
+
+    def __init__(self, lib):
+        self._real = lib
+
+    def __getattr__(self, name):
+        if name in self._NO_HANDLE or name.startswith("rt_multi_"):
+            return getattr(self._real, name)
+        if name == "rt_read_rgba8":
+            return self._real.rt_multi_read_frame_rgba8
+        multi = "rt_multi_" + name[3:]
+        if name.startswith("rt_") and hasattr(self._real, multi):
+            return getattr(self._real, multi)
+        raise AttributeError("%s has no multi-device form (include/rt355.h: rt_multi_*)" % name)
+
+
+class MultiDevice(Device):
+    """Several gfx950 GPUs behind ONE process (``rt_multi_create``): the reference's shape — one process, one loop
+    (app.rs:64-104, 208-254) — with the frame's row strips dealt over the devices and gathered on the first one by peer
+    copies.  Drop-in for ``Device`` wherever the whole frame is meant: ``Connection``, ``RenderTarget``,
+    ``RandomTexture`` and ``render_scene`` work unchanged; ``read_frame_rgba8`` / ``RenderTarget.read_rgba8`` return the
+    assembled frame.  ``device_ids`` may repeat a device (tests on one GPU)."""
+
+    def __init__(self, device_ids, strip_rows: int = 8):
+        real = N.load()
+        self._lib = _MultiLib(real)
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        handle = C.c_void_p()
+        rc = real.rt_multi_create(ids, len(device_ids), strip_rows, C.byref(handle))
+        if rc != N.RT_OK:
+            raise N.RtError(rc, "rt_multi_create(devices %s)" % list(device_ids),
+                            "no usable gfx950 device — rt355 has no CPU fallback")
+        self.handle = handle
+        self.device_id = device_ids[0]
+        self.device_ids = list(device_ids)
+
+    def close(self):
+        if self.handle:
+            self._lib.rt_multi_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def stats(self) -> N.RtStats:
+        st = N.RtStats()
+        self.call("rt_get_stats", C.byref(st))
+        return st
+
+    def member(self, index: int) -> C.c_void_p:
+        """Device ``index``'s rt_context, for per-device calls on the raw library (rt_get_stats, rt_last_error)."""
+        return C.c_void_p(self._lib.rt_multi_context(self.handle, index))
+
+    def set_outputs(self, flags: int):
+        if flags != N.RT_OUT_RGBA8:
+            raise ValueError("an rt_multi renders the sRGB8 target only")
+
+    def set_partition(self, rank: int, world: int, strip_rows: int = 8):
+        raise ValueError("the partition belongs to the rt_multi")
+
+    def read_frame_rgba8(self, width: int, height: int) -> np.ndarray:
+        out = np.empty((height, width, 4), np.uint8)
+        self.call("rt_read_frame_rgba8", out.ctypes.data_as(C.c_void_p), out.nbytes)
+        return out
+
+
 class FrameData:
     """connection.rs:13-40."""
     BUFFER_SIZE = 16

@@ -99,6 +99,11 @@ struct rt_context {
   // send[(k & 1) ^ 1] as its history, so the gather of launch k reads a buffer launch k + 1 does not write.
   ncclComm_t comm = nullptr;
   uint32_t comm_rank = 0, comm_world = 0;
+  // member of a single-process multi-device frame (rt_multi_create): the same alternating targets and rank-0 buffers as with
+  // a communicator (comm_rank / comm_world give the layout), but the gather is driven by the rt_multi that owns the context
+  // (peer copies to device 0) and gather_done[] are its events
+  bool multi_member = false;
+  bool exchanges() const { return comm != nullptr || multi_member; }
   hipStream_t comm_stream = nullptr;
   uint32_t *d_rgba8_alt = nullptr;  // send[1]; send[0] is d_rgba8
   hipEvent_t frame_ready[2] = {nullptr, nullptr}, gather_done[2] = {nullptr, nullptr};
@@ -230,7 +235,7 @@ int alloc_target_buffers(rt_context *ctx, size_t px) {
     RT_HIP(ctx, hipMemsetAsync(ctx->d_hist_f32, 0, px * 12, ctx->stream));
   }
   if (ctx->out_flags & RT_OUT_SEGMENTS) RT_HIP(ctx, hipMalloc(&ctx->d_segments, px * 4));
-  if (ctx->comm) {
+  if (ctx->exchanges()) {
     RT_HIP(ctx, hipMalloc(&ctx->d_rgba8_alt, px * 4));
     RT_HIP(ctx, hipMemsetAsync(ctx->d_rgba8_alt, 0, px * 4, ctx->stream));
     ctx->rank_rows.assign(ctx->comm_world, 0);
@@ -704,7 +709,8 @@ int rt_set_partition(rt_context *ctx, uint32_t rank, uint32_t world, uint32_t st
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!world || rank >= world || !strip_rows)
     return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_partition: rank %u / world %u / strip %u", rank, world, strip_rows);
-  if (ctx->comm) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_partition: the partition belongs to the communicator (rt_comm_init)");
+  if (ctx->exchanges())
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_partition: the partition belongs to the communicator (rt_comm_init) / the rt_multi");
   RT_HIP(ctx, hipSetDevice(ctx->device));
   ctx->rank = rank;
   ctx->world = world;
@@ -868,6 +874,7 @@ int rt_comm_init(rt_context *ctx, const void *id128, uint32_t rank, uint32_t wor
   if (!id128 || !world || rank >= world || !strip_rows || world > kMaxRanks)
     return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_comm_init: rank %u / world %u (1..%u) / strip %u", rank, world, kMaxRanks, strip_rows);
   if (ctx->comm) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_comm_init: the context already has a communicator");
+  if (ctx->multi_member) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_comm_init: the context belongs to an rt_multi");
   std::string why;
   const RcclApi &api = rccl_api(&why);
   if (!api.ok()) return fail(ctx, RT_ERR_NOT_READY, "rt_comm_init: no RCCL library could be loaded (%s)", why.c_str());
@@ -1205,8 +1212,8 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   fp.hist_rgba8 = ctx->ext_rgba8 ? (ctx->ext_hist_rgba8 ? ctx->ext_hist_rgba8 : ctx->ext_rgba8) : ctx->d_rgba8;
   fp.rgbf32 = ctx->ext_rgba8 ? ctx->ext_rgbf32 : ctx->d_rgbf32;
   const int send = static_cast<int>(ctx->comm_launches & 1u);
-  if (ctx->comm) {  // alternate targets: the gather of this launch must not meet the next launch's writes
-    if (ctx->ext_rgba8) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render: rt_bind_outputs and rt_comm_init exclude each other");
+  if (ctx->exchanges()) {  // alternate targets: the gather of this launch must not meet the next launch's writes
+    if (ctx->ext_rgba8) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render: rt_bind_outputs and a multi-GPU frame exclude each other");
     uint32_t *bufs[2] = {ctx->d_rgba8, ctx->d_rgba8_alt};
     fp.rgba8 = bufs[send];
     fp.hist_rgba8 = bufs[send ^ 1];
@@ -1403,6 +1410,8 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   if (ctx->comm) {
     const int grc = gather_frame(ctx, send);
     if (grc != RT_OK) return grc;
+  }
+  if (ctx->exchanges()) {  // (a member of an rt_multi: its owner gathers after all members have launched)
     ctx->last_send = send;
     ctx->comm_launches += 1;
   }
@@ -1463,7 +1472,7 @@ int rt_sync(rt_context *ctx) {
 static const uint32_t *current_texels(rt_context *ctx) {  // caller-bound buffers take precedence
   if (!ctx) return nullptr;
   if (ctx->ext_rgba8) return ctx->ext_rgba8;
-  return (ctx->comm && ctx->last_send) ? ctx->d_rgba8_alt : ctx->d_rgba8;  // comm mode: the target of the last launch
+  return (ctx->exchanges() && ctx->last_send) ? ctx->d_rgba8_alt : ctx->d_rgba8;  // multi-GPU frame: the target of the last launch
 }
 int rt_read_rgba8(rt_context *ctx, void *dst, size_t bytes) {
   return read_back(ctx, current_texels(ctx), dst, bytes, 4, "rt_read_rgba8");
@@ -1524,7 +1533,7 @@ int rt_write_history_rgba8(rt_context *ctx, const void *src, size_t bytes) {
   if (bytes != need) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_write_history_rgba8: %zu bytes given, %zu expected", bytes, need);
   RT_HIP(ctx, hipSetDevice(ctx->device));
   uint32_t *history = ctx->ext_rgba8 ? (ctx->ext_hist_rgba8 ? ctx->ext_hist_rgba8 : ctx->ext_rgba8) : ctx->d_rgba8;
-  if (ctx->comm && !ctx->ext_rgba8) {  // the next launch reads the buffer it does not write ...
+  if (ctx->exchanges() && !ctx->ext_rgba8) {  // the next launch reads the buffer it does not write ...
     const int idx = (ctx->comm_launches & 1u) ? 0 : 1;
     history = idx ? ctx->d_rgba8_alt : ctx->d_rgba8;
     // ... which is the one the previous launch wrote and whose gather may still be sending from it
@@ -1708,6 +1717,237 @@ int rt_selftest_math_binary(rt_context *ctx, int op, const float *a, const float
   (void)hipFree(db);
   (void)hipFree(dy);
   if (rc != 0 || e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "math self-test failed");
+  return RT_OK;
+}
+
+// ---- the multi-GPU frame driven by ONE process (rt_multi_*) -------------------------------------------------------------
+// The reference is one process with one loop (app.rs:208-254).  An rt_multi owns one context per device, gives context i
+// the row strips s with s % n == i, forwards every setter to all of them, launches every render on all of them (the
+// launches are asynchronous: the devices work side by side) and gathers on device 0: peer copies of the members' strips
+// (hipMemcpyPeerAsync: one xGMI link per peer) into the layout rank 0 of a communicator receives, then the same assembly
+// kernel.  Targets alternate exactly as with a communicator, so the gather of launch k runs beside launch k + 1.
+struct rt_multi {
+  std::vector<rt_context *> ctx;
+  uint32_t strip_rows = 8;
+  int device0 = 0;
+  hipStream_t gather_stream = nullptr;
+  hipEvent_t done[2] = {nullptr, nullptr};  // the gather that read target b has finished (recorded on gather_stream)
+  std::string error;
+};
+
+static int multi_fail(rt_multi *m, int code, const char *what, rt_context *from = nullptr) {
+  if (m) m->error = std::string(what) + (from ? std::string(": ") + from->error : std::string());
+  return code;
+}
+
+// after every member has launched: strips -> device 0 -> frame
+static int multi_gather(rt_multi *m) {
+  const uint32_t n = static_cast<uint32_t>(m->ctx.size());
+  rt_context *root = m->ctx[0];
+  const int b = root->last_send;
+  for (uint32_t i = 0; i < n; ++i) {
+    rt_context *c = m->ctx[i];
+    if (c->last_send != b) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: the members' targets are out of step");
+    if (hipSetDevice(c->device) != hipSuccess || hipEventRecord(c->frame_ready[b], c->stream) != hipSuccess)
+      return multi_fail(m, RT_ERR_DEVICE, "rt_multi: recording a frame event failed");
+  }
+  if (hipSetDevice(m->device0) != hipSuccess) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: hipSetDevice failed");
+  for (uint32_t i = 0; i < n; ++i)
+    if (hipStreamWaitEvent(m->gather_stream, m->ctx[i]->frame_ready[b], 0) != hipSuccess)
+      return multi_fail(m, RT_ERR_DEVICE, "rt_multi: waiting for a frame event failed");
+  AssembleParams ap{};
+  fill_assemble_layout(ap, root->width, root->height, n, m->strip_rows);
+  const size_t row_bytes = static_cast<size_t>(root->width) * 4;
+  for (uint32_t i = 1; i < n; ++i) {
+    rt_context *c = m->ctx[i];
+    if (!c->local_rows) continue;
+    const uint32_t *src = b ? c->d_rgba8_alt : c->d_rgba8;
+    if (hipMemcpyPeerAsync(root->d_stack + ap.stack_offset[i], m->device0, src, c->device, c->local_rows * row_bytes, m->gather_stream) !=
+        hipSuccess)
+      return multi_fail(m, RT_ERR_DEVICE, "rt_multi: hipMemcpyPeerAsync failed");
+  }
+  ap.frame = root->d_frame;
+  ap.own = b ? root->d_rgba8_alt : root->d_rgba8;
+  ap.stack = root->d_stack;
+  if (launch_assemble(ap, m->gather_stream) != 0) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: assemble launch failed");
+  if (hipEventRecord(m->done[b], m->gather_stream) != hipSuccess) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: recording the gather event failed");
+  for (uint32_t i = 0; i < n; ++i) m->ctx[i]->gather_pending[b] = true;  // target b is written again only after this gather
+  return RT_OK;
+}
+
+#define RT_MULTI_EACH(m, what, call)                                              \
+  do {                                                                            \
+    if (!(m)) return RT_ERR_INVALID_ARGUMENT;                                     \
+    for (rt_context * c_ : (m)->ctx) {                                            \
+      const int rc_ = (call);                                                     \
+      if (rc_ != RT_OK) return multi_fail((m), rc_, what, c_);                    \
+    }                                                                             \
+  } while (0)
+
+int rt_multi_destroy(rt_multi *m) {
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  for (rt_context *c : m->ctx) {  // everything in flight first: the members' streams, then the gathers that read them
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+  }
+  (void)hipSetDevice(m->device0);
+  if (m->gather_stream) (void)hipStreamSynchronize(m->gather_stream);
+  for (rt_context *c : m->ctx) {
+    c->gather_done[0] = c->gather_done[1] = nullptr;  // the rt_multi's events, not the context's
+    c->gather_pending[0] = c->gather_pending[1] = false;
+    (void)rt_destroy(c);
+  }
+  (void)hipSetDevice(m->device0);
+  for (int b = 0; b < 2; ++b)
+    if (m->done[b]) (void)hipEventDestroy(m->done[b]);
+  if (m->gather_stream) (void)hipStreamDestroy(m->gather_stream);
+  delete m;
+  return RT_OK;
+}
+
+int rt_multi_create(const int *device_ids, uint32_t n_devices, uint32_t strip_rows, rt_multi **out) {
+  if (!out) return RT_ERR_INVALID_ARGUMENT;
+  *out = nullptr;
+  if (!device_ids || !n_devices || n_devices > kMaxRanks || !strip_rows) return RT_ERR_INVALID_ARGUMENT;
+  rt_multi *m = new (std::nothrow) rt_multi();
+  if (!m) return RT_ERR_OUT_OF_MEMORY;
+  m->strip_rows = strip_rows;
+  m->device0 = device_ids[0];
+  auto bail = [&](int code) {
+    rt_multi_destroy(m);
+    return code;
+  };
+  for (uint32_t i = 0; i < n_devices; ++i) {
+    rt_context *c = nullptr;
+    const int rc = rt_create(device_ids[i], &c);
+    if (rc != RT_OK) return bail(rc);
+    m->ctx.push_back(c);
+    c->multi_member = true;
+    c->rank = c->comm_rank = i;
+    c->world = c->comm_world = n_devices;
+    c->strip_rows = strip_rows;
+    c->out_flags = RT_OUT_RGBA8;
+    for (int b = 0; b < 2; ++b)
+      if (hipEventCreateWithFlags(&c->frame_ready[b], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
+  }
+  if (hipSetDevice(m->device0) != hipSuccess) return bail(RT_ERR_DEVICE);
+  if (hipStreamCreateWithFlags(&m->gather_stream, hipStreamNonBlocking) != hipSuccess) return bail(RT_ERR_DEVICE);
+  for (int b = 0; b < 2; ++b)
+    if (hipEventCreateWithFlags(&m->done[b], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
+  for (rt_context *c : m->ctx) {
+    c->gather_done[0] = m->done[0];
+    c->gather_done[1] = m->done[1];
+    if (c->device != m->device0) {  // direct peer copies where the devices can (xGMI); otherwise the runtime stages them
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, m->device0, c->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(c->device, 0);
+      (void)hipGetLastError();  // "already enabled" is not an error
+    }
+  }
+  *out = m;
+  return RT_OK;
+}
+
+uint32_t rt_multi_device_count(rt_multi *m) { return m ? static_cast<uint32_t>(m->ctx.size()) : 0u; }
+rt_context *rt_multi_context(rt_multi *m, uint32_t index) { return (m && index < m->ctx.size()) ? m->ctx[index] : nullptr; }
+const char *rt_multi_last_error(rt_multi *m) { return m ? m->error.c_str() : "rt_multi is NULL"; }
+
+int rt_multi_set_skybox(rt_multi *m, uint32_t width, uint32_t height, const float *rgba32f) {
+  RT_MULTI_EACH(m, "rt_multi_set_skybox", rt_set_skybox(c_, width, height, rgba32f));
+  return RT_OK;
+}
+int rt_multi_set_skybox_exr(rt_multi *m, const char *path) {
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  uint32_t w = 0, h = 0;
+  float *texels = nullptr;
+  const int rc = rt_exr_read_rgba32f(path, &w, &h, &texels);  // decoded once, uploaded to every device
+  if (rc != RT_OK) return multi_fail(m, rc, rt_exr_last_error());
+  const int rc2 = rt_multi_set_skybox(m, w, h, texels);
+  rt_exr_free(texels);
+  return rc2;
+}
+int rt_multi_set_random(rt_multi *m, uint32_t width, uint32_t height, const float *r32f) {
+  RT_MULTI_EACH(m, "rt_multi_set_random", rt_set_random(c_, width, height, r32f));
+  return RT_OK;
+}
+int rt_multi_generate_random(rt_multi *m, uint32_t width, uint32_t height, uint64_t seed) {
+  RT_MULTI_EACH(m, "rt_multi_generate_random", rt_generate_random(c_, width, height, seed));
+  return RT_OK;
+}
+int rt_multi_set_scene(rt_multi *m, const void *objects, uint32_t object_count, const void *lights, uint32_t light_count,
+                       const void *config112) {
+  RT_MULTI_EACH(m, "rt_multi_set_scene", rt_set_scene(c_, objects, object_count, lights, light_count, config112));
+  return RT_OK;
+}
+int rt_multi_resize(rt_multi *m, uint32_t width, uint32_t height) {
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(m->device0);
+  (void)hipStreamSynchronize(m->gather_stream);  // a gather may still read the buffers about to be replaced
+  RT_MULTI_EACH(m, "rt_multi_resize", rt_resize(c_, width, height));
+  return RT_OK;
+}
+int rt_multi_set_accum_mode(rt_multi *m, int mode) {
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(m->device0);
+  (void)hipStreamSynchronize(m->gather_stream);
+  RT_MULTI_EACH(m, "rt_multi_set_accum_mode", rt_set_accum_mode(c_, mode));
+  return RT_OK;
+}
+int rt_multi_set_option(rt_multi *m, int option, int value) {
+  RT_MULTI_EACH(m, "rt_multi_set_option", rt_set_option(c_, option, value));
+  return RT_OK;
+}
+int rt_multi_render_frames(rt_multi *m, uint32_t n_frames, const void *framedata16) {
+  RT_MULTI_EACH(m, "rt_multi_render_frames", rt_render_frames(c_, n_frames, framedata16));
+  return multi_gather(m);
+}
+int rt_multi_render_frame(rt_multi *m, const void *framedata16) {
+  RT_MULTI_EACH(m, "rt_multi_render_frame", rt_render_frame(c_, framedata16));
+  return multi_gather(m);
+}
+int rt_multi_render(rt_multi *m, float jitter_x, float jitter_y, uint32_t progressive_count) {
+  RT_MULTI_EACH(m, "rt_multi_render", rt_render(c_, jitter_x, jitter_y, progressive_count));
+  return multi_gather(m);
+}
+int rt_multi_sync(rt_multi *m) {
+  RT_MULTI_EACH(m, "rt_multi_sync", rt_sync(c_));
+  if (hipSetDevice(m->device0) != hipSuccess || hipStreamSynchronize(m->gather_stream) != hipSuccess)
+    return multi_fail(m, RT_ERR_DEVICE, "rt_multi_sync: the gather stream failed");
+  return RT_OK;
+}
+int rt_multi_read_frame_rgba8(rt_multi *m, void *dst, size_t bytes) {
+  if (!m || !dst) return RT_ERR_INVALID_ARGUMENT;
+  rt_context *root = m->ctx[0];
+  if (!root->d_frame) return multi_fail(m, RT_ERR_NOT_READY, "rt_multi_read_frame_rgba8: no target (rt_multi_resize)");
+  const size_t need = static_cast<size_t>(root->width) * root->height * 4;
+  if (bytes != need) return multi_fail(m, RT_ERR_INVALID_ARGUMENT, "rt_multi_read_frame_rgba8: wrong size");
+  if (hipSetDevice(m->device0) != hipSuccess ||
+      hipMemcpyAsync(dst, root->d_frame, bytes, hipMemcpyDeviceToHost, m->gather_stream) != hipSuccess ||  // behind the last gather
+      hipStreamSynchronize(m->gather_stream) != hipSuccess)
+    return multi_fail(m, RT_ERR_DEVICE, "rt_multi_read_frame_rgba8: copy failed");
+  return RT_OK;
+}
+int rt_multi_get_stats(rt_multi *m, rt_stats *out) {
+  if (!m || !out) return RT_ERR_INVALID_ARGUMENT;
+  rt_stats sum{};
+  bool first = true;
+  for (rt_context *c : m->ctx) {
+    rt_stats st{};
+    const int rc = rt_get_stats(c, &st);
+    if (rc != RT_OK) return multi_fail(m, rc, "rt_multi_get_stats", c);
+    if (first) {
+      sum = st;
+      first = false;
+      continue;
+    }
+    sum.last_segments += st.last_segments;
+    sum.last_rough_hits += st.last_rough_hits;
+    sum.last_pixels += st.last_pixels;
+    sum.local_rows += st.local_rows;
+    sum.last_wave_iterations += st.last_wave_iterations;
+    sum.last_cull_mismatches += st.last_cull_mismatches;
+    if (st.last_kernel_ms > sum.last_kernel_ms) sum.last_kernel_ms = st.last_kernel_ms;  // the devices run side by side
+  }
+  *out = sum;
   return RT_OK;
 }
 

@@ -1,0 +1,113 @@
+"""The multi-GPU frame driven by ONE process (rt_multi_*, include/rt355.h) — the reference's shape: one process, one loop
+(app.rs:208-254).  The GPU box has one device, so the rt_multi binds it several times: every context renders its strips,
+the peer copies and the assembly on the first context run exactly as they would across devices.  Frames must be the
+oracle's, bit for bit, through single frames (several in flight), multi-frame launches and both accumulation modes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from rsraytracingv3_amd import Connection, MultiDevice, RandomTexture, RenderTarget, synth
+from rsraytracingv3_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_chain(scene, size, sky, rnd, jitters, first_count, accum):
+    w, h = size
+    objects, count, cfg = scene.live_object_bytes(), len(scene.objects), scene.config_bytes(w, h)
+    hist8 = histf = None
+    frames = []
+    for k, jit in enumerate(jitters):
+        ref = oracle.render(objects, count, cfg, (float(jit[0]), float(jit[1])), first_count + k, sky, rnd, history_rgba8=hist8,
+                            history_f32=histf, accum_mode=accum, want_hits=False, threads=8)
+        hist8, histf = (None, ref.rgbf32) if accum == 1 else (ref.rgba8, None)
+        frames.append(ref)
+    return frames
+
+
+@pytest.mark.parametrize("n_dev,strip", [(1, 8), (2, 8), (3, 8), (8, 8), (5, 3)])
+def test_one_process_drives_every_device_and_the_frame_is_the_oracles(n_dev, strip):
+    scene = cases.headline_scene(4)
+    size = (333, 171)  # ragged: the last strip is short, devices own different row counts
+    sky, rnd = cases.inputs(128, 64)
+    jit = synth.jitter_sequence(9, 16)
+    dev = MultiDevice([0] * n_dev, strip)
+    try:
+        for accum in (N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32):
+            dev.set_accum_mode(accum)
+            target = RenderTarget.new(dev, size)
+            rt = RandomTexture(dev)
+            rt.write(rnd)
+            conn = Connection(scene, dev, sky, rt, max_objects="live")
+            conn.update_buffers(size, scene, (0.0, 0.0))
+            want = oracle_chain(scene, size, sky, rnd, jit[:10], 0, 1 if accum == N.RT_ACCUM_FLOAT32 else 0)
+            k = 0
+            for launch in (1, 1, 1, 4, 1, 2):  # frames per launch; the single frames overlap on the devices' internal streams
+                if launch == 1:
+                    conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
+                    conn.frame_data.progressive_count = k
+                    conn.draw()
+                else:
+                    conn.draw_frames(jit[k:k + launch], k)
+                k += launch
+                if launch != 2:  # leave one gather un-read: the next launch overlaps it
+                    frame = dev.read_frame_rgba8(*size)
+                    assert np.array_equal(frame, want[k - 1].rgba8), "after %d frames, accumulation mode %d" % (k, accum)
+            dev.sync()
+            assert np.array_equal(target.read_rgba8(), want[k - 1].rgba8)
+            st = dev.stats()
+            assert st.local_rows == size[1] and st.last_pixels == 2 * size[0] * size[1]  # the last launch carried two frames
+            assert st.last_segments == int(want[k - 2].segments.sum()) + int(want[k - 1].segments.sum())
+        assert dev._lib.rt_multi_device_count(dev.handle) == n_dev
+    finally:
+        dev.close()
+
+
+def test_members_keep_their_partition_and_report_their_own_share():
+    scene = cases.headline_scene(3)
+    size = (160, 90)
+    sky, rnd = cases.inputs(64, 32)
+    dev = MultiDevice([0, 0, 0], 8)
+    try:
+        RenderTarget.new(dev, size)
+        rt = RandomTexture(dev)
+        rt.write(rnd)
+        conn = Connection(scene, dev, sky, rt, max_objects="live")
+        conn.update_buffers(size, scene, (0.0, 0.0))
+        conn.draw()
+        dev.sync()
+        lib = N.load()
+        rows = []
+        for i in range(3):
+            member = dev.member(i)
+            st = N.RtStats()
+            assert lib.rt_get_stats(member, C.byref(st)) == 0
+            rows.append(st.local_rows)
+            assert lib.rt_set_partition(member, 0, 1, 8) == -1            # the partition belongs to the rt_multi
+            assert b"rt_multi" in lib.rt_last_error(member)
+        assert rows == [32, 32, 26] and sum(rows) == size[1]                # strips of 8 rows dealt 0, 1, 2, 0, 1, 2, ...
+        # a second size: every member's buffers and the first one's frame are replaced
+        size2 = (96, 40)
+        RenderTarget.new(dev, size2)
+        conn.last_size = (0, 0)
+        conn.update_buffers(size2, scene, (0.0, 0.0))
+        conn.frame_data.progressive_count = 0
+        conn.draw()
+        ref = oracle.render(scene.live_object_bytes(), len(scene.objects), scene.config_bytes(*size2), conn.frame_data.jitter, 0,
+                            sky, rnd, want_hits=False, threads=4)
+        assert np.array_equal(dev.read_frame_rgba8(*size2), ref.rgba8)
+    finally:
+        dev.close()
+
+
+def test_create_refuses_nonsense():
+    lib = N.load()
+    handle = C.c_void_p()
+    ids = (C.c_int * 1)(0)
+    assert lib.rt_multi_create(ids, 0, 8, C.byref(handle)) == -1 and not handle.value
+    assert lib.rt_multi_create(ids, 1, 0, C.byref(handle)) == -1
+    bad = (C.c_int * 2)(0, 99)
+    assert lib.rt_multi_create(bad, 2, 8, C.byref(handle)) == -2 and not handle.value   # RT_ERR_NO_DEVICE, nothing leaked
