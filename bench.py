@@ -394,7 +394,9 @@ def main():
             continue
         prof_key = dict(prof.get("workload_key", {}))
         prof_key.pop("frames_per_launch", None)  # the profile's launches carried 8 frames; traffic is taken per frame
-        if prof_key != workload_key or B <= 1:
+        tuned = (args.variant != -1 or args.dirmask >= 0 or args.dirmask_k or args.dirmask_cells or args.grid_min or args.flags or
+                 args.batch_inflight != 1 or args.blocks_per_cu or args.refill_min != 1 or args.tile_chunk != 2)
+        if prof_key != workload_key or B <= 1 or tuned:  # the profile was collected with the library's defaults
             continue
         if prof.get("kernel_source_sha256") != source_now:
             traffic_source = {"file": "profiles/" + name, "used": False,
