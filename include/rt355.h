@@ -190,7 +190,10 @@ RT355_API int rt_read_frame_rgba8(rt_context *ctx, void *dst, size_t bytes);
  * side — and then gathers on device_ids[0]: peer copies of the other devices' strips (hipMemcpyPeerAsync, one xGMI link per
  * peer, no ring) into the layout rank 0 of a communicator receives, then the same assembly kernel; targets alternate, so
  * the gather of launch k runs beside launch k + 1.  rt_multi_read_frame_rgba8 returns the assembled height x width frame,
- * bit-identical to the single-GPU frame.  device_ids may name one device several times (what the tests do on one GPU).
+ * bit-identical to the single-GPU frame.  rt_multi_set_random / rt_multi_generate_random are thread-safe against the render
+ * calls, and the texture changes on all devices between two launches: a frame sees ONE texture in every strip
+ * (random_texture.rs:56-61 refreshes it from a thread of its own).  device_ids may name one device several times (what the
+ * tests do on one GPU).
  * rt_multi_context(m, i) is device i's context for per-device calls (rt_get_stats, rt_set_option, rt_last_error); do not
  * render, resize or destroy through it.  No RCCL involved; use rt_comm_init when the ranks are separate processes. */
 typedef struct rt_multi rt_multi;

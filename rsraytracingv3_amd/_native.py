@@ -140,12 +140,13 @@ _lib = None
 
 def kernel_source_hash() -> str:
     """sha256 over the sources that decide what the render kernels do and how they are launched (csrc/rt_kernels.hip,
-    rt_shim.hip, rt_device.h, rt_math.h, rt_dirmask.h, rt_grid.h, Makefile), in name order.  Profiles record it
+    rt_device.h — which also holds the defaults of the launch-shaping options —, rt_math.h, rt_dirmask.h, rt_grid.h,
+    Makefile), in name order.  Profiles record it
     (tools/pmc_summary.py) and bench.py only quotes a profile's counters when the tree it runs from still has the sources
     the profile was measured on."""
     import hashlib
     h = hashlib.sha256()
-    names = ("Makefile", "rt_device.h", "rt_dirmask.h", "rt_grid.h", "rt_kernels.hip", "rt_math.h", "rt_shim.hip")
+    names = ("Makefile", "rt_device.h", "rt_dirmask.h", "rt_grid.h", "rt_kernels.hip", "rt_math.h")
     files = [os.path.join(_HERE, "csrc", n) for n in names]
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")

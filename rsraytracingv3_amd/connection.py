@@ -150,15 +150,17 @@ class _MultiLib:
     def __init__(self, lib):
         self._real = lib
 
-    def __getattr__(self, name):
+    def __getattr__(self, name):  # called once per name: the resolved entry point is kept on the instance
         if name in self._NO_HANDLE or name.startswith("rt_multi_"):
-            return getattr(self._real, name)
-        if name == "rt_read_rgba8":
-            return self._real.rt_multi_read_frame_rgba8
-        multi = "rt_multi_" + name[3:]
-        if name.startswith("rt_") and hasattr(self._real, multi):
-            return getattr(self._real, multi)
-        raise AttributeError("%s has no multi-device form (include/rt355.h: rt_multi_*)" % name)
+            fn = getattr(self._real, name)
+        elif name == "rt_read_rgba8":
+            fn = self._real.rt_multi_read_frame_rgba8
+        elif name.startswith("rt_") and hasattr(self._real, "rt_multi_" + name[3:]):
+            fn = getattr(self._real, "rt_multi_" + name[3:])
+        else:
+            raise AttributeError("%s has no multi-device form (include/rt355.h: rt_multi_*)" % name)
+        setattr(self, name, fn)
+        return fn
 
 
 class MultiDevice(Device):

@@ -71,6 +71,15 @@ struct DeviceScene {
 };
 constexpr uint32_t kImageLdsRecords = 1024;  // 16 KB: scenes up to ~300 spheres are staged whole
 
+// Defaults of the options that decide which kernels a launch runs and on what (rt_set_option); they live here, with the
+// kernels, because profiles are tied to the sources that shape the measured launches (_native.kernel_source_hash).
+constexpr int kDefaultDirmaskMinSpheres = 26;  // RT_OPT_DIRMASK_MIN
+constexpr int kDefaultDirmaskCells = 4096;     // RT_OPT_DIRMASK_CELLS
+constexpr int kDefaultDirmaskK = 12;           // RT_OPT_DIRMASK_K
+constexpr int kDefaultGridMinSpheres = 129;    // RT_OPT_GRID_MIN
+constexpr int kDefaultInflight = 4;            // RT_OPT_INFLIGHT
+constexpr int kDefaultBatchInflight = 1;       // RT_OPT_BATCH_INFLIGHT
+
 struct FrameParams {
   uint32_t width, height;      // full frame (Config.width/height, scene.rs:267-268)
   uint32_t reflection_limit;   // Config.reflection_limit

@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -121,22 +123,22 @@ struct rt_context {
   int occupancy_blocks = 0;          // cached hipOccupancyMaxActiveBlocksPerMultiprocessor answer for ...
   uint32_t occupancy_records = ~0u;  // ... a scene image of this many records
   static constexpr int kMaxInflight = 8;
-  int inflight = 4;
-  int batch_inflight = 1;  // RT_OPT_BATCH_INFLIGHT
+  int inflight = kDefaultInflight;
+  int batch_inflight = kDefaultBatchInflight;  // RT_OPT_BATCH_INFLIGHT
   uint64_t prep_generation = 0;                 // bumped whenever prep_done is re-recorded
   uint64_t prep_seen[kMaxInflight] = {};        // generation each render stream has already waited for
   // direction masks (rt_dirmask.h): table of candidate-sphere sets for the secondary rays of scenes with up to 64 spheres
   int dirmask_on = 1;            // RT_OPT_DIRMASK
-  int dirmask_min_spheres = 26;  // RT_OPT_DIRMASK_MIN: smaller scenes scan linearly (the lookup costs more than their scan: A/B on one
+  int dirmask_min_spheres = kDefaultDirmaskMinSpheres;  // RT_OPT_DIRMASK_MIN: smaller scenes scan linearly (the lookup costs more than their scan: A/B on one
                                  // device, table / linear in Grays/s: 16 spheres 57.4 / 59.9, 24: 53.0 / 53.0, 28: 51.6 / 49.6, 32: 51.7 / 49.7,
                                  // 48: 49.2 / 44.0, 64: 46.9 / 38.7)
-  int dirmask_cells = 4096;      // RT_OPT_DIRMASK_CELLS: cells aimed at
-  int dirmask_k = 12;            // RT_OPT_DIRMASK_K: bins per cube-map face edge
+  int dirmask_cells = kDefaultDirmaskCells;      // RT_OPT_DIRMASK_CELLS: cells aimed at
+  int dirmask_k = kDefaultDirmaskK;            // RT_OPT_DIRMASK_K: bins per cube-map face edge
   unsigned long long *d_dirmask = nullptr;
   size_t dirmask_cap = 0;        // in 64-bit words
   float4 *d_dirmask_reg = nullptr;
   std::vector<float4> dirmask_built_for;  // sphere records (+ one record of options) the table on the device was built from
-  int grid_min_spheres = 129;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid; up to 128 spheres the
+  int grid_min_spheres = kDefaultGridMinSpheres;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid; up to 128 spheres the
                                // direction-mask table serves (A/B on one device, tools/dirmask_sweep.sh, Grays/s table / grid / linear:
                                // 80 spheres 60.0 / 47.3 / 45.7, 96: 53.8 / 45.3 / 40.3, 128: 40.6 / 40.3 / 30.6 before the re-packing
                                // shape took 128-sphere scenes; round 2's linear / grid crossover was 88)
@@ -1732,6 +1734,20 @@ struct rt_multi {
   int device0 = 0;
   hipStream_t gather_stream = nullptr;
   hipEvent_t done[2] = {nullptr, nullptr};  // the gather that read target b has finished (recorded on gather_stream)
+  // rt_multi_set_random / rt_multi_generate_random may come from another thread (the reference refreshes the texture every
+  // 4 ms on a thread of its own, random_texture.rs:56-61): the texture changes on ALL devices between two launches, never
+  // while one launch is being issued device by device — a frame sees one texture in every strip
+  std::mutex random_mutex;
+  // One host thread per device issues that device's launches: a launch costs ~20 us of host time, which one thread pays
+  // n times per frame in turn (8 devices: 0.2 ms, more than a device's share of the frame takes to render).
+  std::vector<std::thread> workers;
+  std::mutex job_mutex;
+  std::condition_variable job_cv, done_cv;
+  uint64_t job_generation = 0;
+  uint32_t job_pending = 0;
+  bool quit = false;
+  std::function<int(rt_context *)> job;
+  std::vector<int> job_result;
   std::string error;
 };
 
@@ -1740,9 +1756,56 @@ static int multi_fail(rt_multi *m, int code, const char *what, rt_context *from 
   return code;
 }
 
+static void multi_worker(rt_multi *m, uint32_t index) {
+  uint64_t seen = 0;
+  for (;;) {
+    std::function<int(rt_context *)> job;
+    {
+      std::unique_lock<std::mutex> lock(m->job_mutex);
+      m->job_cv.wait(lock, [&] { return m->quit || m->job_generation != seen; });
+      if (m->quit) return;
+      seen = m->job_generation;
+      job = m->job;
+    }
+    const int rc = job(m->ctx[index]);
+    {
+      std::lock_guard<std::mutex> lock(m->job_mutex);
+      m->job_result[index] = rc;
+      m->job_pending -= 1;
+    }
+    m->done_cv.notify_one();
+  }
+}
+
+// `fn` on every member, each on its device's own host thread (inline when there is one device); the first failure wins
+static int multi_run(rt_multi *m, const char *what, const std::function<int(rt_context *)> &fn) {
+  if (m->workers.empty()) {
+    for (rt_context *c : m->ctx) {
+      const int rc = fn(c);
+      if (rc != RT_OK) return multi_fail(m, rc, what, c);
+    }
+    return RT_OK;
+  }
+  {
+    std::lock_guard<std::mutex> lock(m->job_mutex);
+    m->job = fn;
+    m->job_pending = static_cast<uint32_t>(m->ctx.size());
+    m->job_generation += 1;
+  }
+  m->job_cv.notify_all();
+  {
+    std::unique_lock<std::mutex> lock(m->job_mutex);
+    m->done_cv.wait(lock, [&] { return m->job_pending == 0; });
+  }
+  for (size_t i = 0; i < m->ctx.size(); ++i)
+    if (m->job_result[i] != RT_OK) return multi_fail(m, m->job_result[i], what, m->ctx[i]);
+  return RT_OK;
+}
+
 // after every member has launched: strips -> device 0 -> frame
 static int multi_gather(rt_multi *m) {
   const uint32_t n = static_cast<uint32_t>(m->ctx.size());
+  if (n == 1u) return RT_OK;  // one device: its target is the frame
   rt_context *root = m->ctx[0];
   const int b = root->last_send;
   for (uint32_t i = 0; i < n; ++i) {
@@ -1786,6 +1849,12 @@ static int multi_gather(rt_multi *m) {
 
 int rt_multi_destroy(rt_multi *m) {
   if (!m) return RT_ERR_INVALID_ARGUMENT;
+  {
+    std::lock_guard<std::mutex> lock(m->job_mutex);
+    m->quit = true;
+  }
+  m->job_cv.notify_all();
+  for (std::thread &t : m->workers) t.join();
   for (rt_context *c : m->ctx) {  // everything in flight first: the members' streams, then the gathers that read them
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -1822,11 +1891,12 @@ int rt_multi_create(const int *device_ids, uint32_t n_devices, uint32_t strip_ro
     const int rc = rt_create(device_ids[i], &c);
     if (rc != RT_OK) return bail(rc);
     m->ctx.push_back(c);
+    c->out_flags = RT_OUT_RGBA8;
+    if (n_devices == 1u) continue;  // one device: a plain context, no strips, no gather
     c->multi_member = true;
     c->rank = c->comm_rank = i;
     c->world = c->comm_world = n_devices;
     c->strip_rows = strip_rows;
-    c->out_flags = RT_OUT_RGBA8;
     for (int b = 0; b < 2; ++b)
       if (hipEventCreateWithFlags(&c->frame_ready[b], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
   }
@@ -1835,12 +1905,21 @@ int rt_multi_create(const int *device_ids, uint32_t n_devices, uint32_t strip_ro
   for (int b = 0; b < 2; ++b)
     if (hipEventCreateWithFlags(&m->done[b], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
   for (rt_context *c : m->ctx) {
+    if (!c->multi_member) continue;
     c->gather_done[0] = m->done[0];
     c->gather_done[1] = m->done[1];
     if (c->device != m->device0) {  // direct peer copies where the devices can (xGMI); otherwise the runtime stages them
       int can = 0;
       if (hipDeviceCanAccessPeer(&can, m->device0, c->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(c->device, 0);
       (void)hipGetLastError();  // "already enabled" is not an error
+    }
+  }
+  if (n_devices > 1u) {
+    m->job_result.assign(n_devices, RT_OK);
+    try {
+      for (uint32_t i = 0; i < n_devices; ++i) m->workers.emplace_back(multi_worker, m, i);
+    } catch (...) {
+      return bail(RT_ERR_OUT_OF_MEMORY);
     }
   }
   *out = m;
@@ -1866,10 +1945,14 @@ int rt_multi_set_skybox_exr(rt_multi *m, const char *path) {
   return rc2;
 }
 int rt_multi_set_random(rt_multi *m, uint32_t width, uint32_t height, const float *r32f) {
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(m->random_mutex);
   RT_MULTI_EACH(m, "rt_multi_set_random", rt_set_random(c_, width, height, r32f));
   return RT_OK;
 }
 int rt_multi_generate_random(rt_multi *m, uint32_t width, uint32_t height, uint64_t seed) {
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(m->random_mutex);
   RT_MULTI_EACH(m, "rt_multi_generate_random", rt_generate_random(c_, width, height, seed));
   return RT_OK;
 }
@@ -1897,15 +1980,30 @@ int rt_multi_set_option(rt_multi *m, int option, int value) {
   return RT_OK;
 }
 int rt_multi_render_frames(rt_multi *m, uint32_t n_frames, const void *framedata16) {
-  RT_MULTI_EACH(m, "rt_multi_render_frames", rt_render_frames(c_, n_frames, framedata16));
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  {
+    std::lock_guard<std::mutex> lock(m->random_mutex);  // every device launches with the same random texture
+    const int rc = multi_run(m, "rt_multi_render_frames", [=](rt_context *c) { return rt_render_frames(c, n_frames, framedata16); });
+    if (rc != RT_OK) return rc;
+  }
   return multi_gather(m);
 }
 int rt_multi_render_frame(rt_multi *m, const void *framedata16) {
-  RT_MULTI_EACH(m, "rt_multi_render_frame", rt_render_frame(c_, framedata16));
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  {
+    std::lock_guard<std::mutex> lock(m->random_mutex);
+    const int rc = multi_run(m, "rt_multi_render_frame", [=](rt_context *c) { return rt_render_frame(c, framedata16); });
+    if (rc != RT_OK) return rc;
+  }
   return multi_gather(m);
 }
 int rt_multi_render(rt_multi *m, float jitter_x, float jitter_y, uint32_t progressive_count) {
-  RT_MULTI_EACH(m, "rt_multi_render", rt_render(c_, jitter_x, jitter_y, progressive_count));
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  {
+    std::lock_guard<std::mutex> lock(m->random_mutex);
+    const int rc = multi_run(m, "rt_multi_render", [=](rt_context *c) { return rt_render(c, jitter_x, jitter_y, progressive_count); });
+    if (rc != RT_OK) return rc;
+  }
   return multi_gather(m);
 }
 int rt_multi_sync(rt_multi *m) {
@@ -1917,6 +2015,10 @@ int rt_multi_sync(rt_multi *m) {
 int rt_multi_read_frame_rgba8(rt_multi *m, void *dst, size_t bytes) {
   if (!m || !dst) return RT_ERR_INVALID_ARGUMENT;
   rt_context *root = m->ctx[0];
+  if (m->ctx.size() == 1u) {
+    const int rc = rt_read_rgba8(root, dst, bytes);
+    return rc == RT_OK ? RT_OK : multi_fail(m, rc, "rt_multi_read_frame_rgba8", root);
+  }
   if (!root->d_frame) return multi_fail(m, RT_ERR_NOT_READY, "rt_multi_read_frame_rgba8: no target (rt_multi_resize)");
   const size_t need = static_cast<size_t>(root->width) * root->height * 4;
   if (bytes != need) return multi_fail(m, RT_ERR_INVALID_ARGUMENT, "rt_multi_read_frame_rgba8: wrong size");

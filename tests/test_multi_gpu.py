@@ -111,3 +111,53 @@ def test_create_refuses_nonsense():
     assert lib.rt_multi_create(ids, 1, 0, C.byref(handle)) == -1
     bad = (C.c_int * 2)(0, 99)
     assert lib.rt_multi_create(bad, 2, 8, C.byref(handle)) == -2 and not handle.value   # RT_ERR_NO_DEVICE, nothing leaked
+
+
+def test_random_texture_thread_never_splits_a_frame_between_two_textures():
+    """rt_multi_set_random from another thread while frames render on three members (random_texture.rs:56-61): every
+    assembled frame must be the oracle's frame for ONE of the two textures in ALL of its strips."""
+    import threading
+    import time
+    scene = cases.headline_scene(6)
+    sky = synth.procedural_skybox(64, 32)
+    tex = [synth.random_texture(11), synth.random_texture(12)]
+    size = (96, 54)
+    refs = [oracle.render(scene.live_object_bytes(), len(scene.objects), scene.config_bytes(*size), (0.2, -0.3), 0, sky, t,
+                          want_hits=False, threads=4).rgba8 for t in tex]
+    assert not np.array_equal(refs[0], refs[1])
+    dev = MultiDevice([0, 0, 0], 8)
+    try:
+        RenderTarget.new(dev, size)
+        rt = RandomTexture(dev)
+        rt.write(tex[0])
+        conn = Connection(scene, dev, sky, rt, max_objects="live")
+        conn.update_buffers(size, scene, (0.2, -0.3))
+        stop, errors = threading.Event(), []
+
+        def writer():
+            k = 0
+            while not stop.is_set():
+                k ^= 1
+                rc = dev._lib.rt_set_random(dev.handle, 600, 600, tex[k].ctypes.data_as(C.c_void_p))
+                if rc != 0:
+                    errors.append(rc)
+
+        th = threading.Thread(target=writer)
+        th.start()
+        try:
+            seen, frames, deadline = [0, 0], 0, time.time() + 20.0
+            while (min(seen) < 5 or frames < 60) and time.time() < deadline:
+                conn.frame_data.jitter, conn.frame_data.progressive_count = (0.2, -0.3), 0
+                conn.draw()
+                got = dev.read_frame_rgba8(*size)
+                which = [np.array_equal(got, r) for r in refs]
+                assert any(which), "the assembled frame matches neither texture: strips rendered with different textures"
+                seen[which.index(True)] += 1
+                frames += 1
+                time.sleep(0.0005)
+        finally:
+            stop.set()
+            th.join()
+        assert not errors and min(seen) > 0
+    finally:
+        dev.close()
