@@ -1325,8 +1325,8 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
         q[0] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
         q[1] = make_float4(s.d.y, s.d.z, s.energy.x, s.energy.y);
         q[2] = make_float4(s.energy.z, s.result.x, s.result.y, s.result.z);
-        q[3] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p | (s.seg << 26)));
-        q[4] = make_float4(h.t, __int_as_float(h.slot), __int_as_float(h.obj), __uint_as_float(h.plane ? 1u : 0u));
+        q[3] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p));
+        q[4] = make_float4(h.t, __int_as_float(h.slot), __int_as_float(h.obj), __uint_as_float((h.plane ? 1u : 0u) | (s.seg << 1)));
       }
       if (finished) {  // the lane's registers are about to change hands
         path_end<RT_DEFER_SKY_BLOCKS, LEAN>(fp, s);
@@ -1345,14 +1345,13 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
         s.energy = mk3(b.z, b.w, c.x);
         s.result = mk3(c.y, c.z, c.w);
         s.rng = Rng{e.x, e.y, e.z};
-        const uint32_t packed = __float_as_uint(e.w);
-        s.p = packed & 0x03ffffffu;
-        s.seg = packed >> 26;
+        s.p = __float_as_uint(e.w);  // the whole word: a launch may carry up to 2^32 pixels (64 frames of 1080p are 2^27)
+        s.seg = __float_as_uint(g.w) >> 1;
         s.rough = 0;
         h.t = g.x;
         h.slot = __float_as_int(g.y);
         h.obj = __float_as_int(g.z);
-        h.plane = __float_as_uint(g.w) != 0u;
+        h.plane = (__float_as_uint(g.w) & 1u) != 0u;
       }
       live_waves = need;
       // No barrier here: the exchange buffer is next written after the next count barrier, which the
@@ -2004,8 +2003,10 @@ int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfi
   }
   // the streamed shape writes float samples only and needs its queue
   if (variant == 4 && !sample_only(fp)) variant = 3;
-  // the packed path state keeps 6 bits of bounce count and 26 bits of pixel index
-  if ((variant == 3 || variant == 4) && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26))) variant = 0;
+  // the packed path state of the streamed shape (and of the re-packing shape when it packs after the shading) keeps 6 bits of
+  // bounce count and 26 bits of pixel index; the default re-packing shape carries both in full
+  if ((variant == 4 || (variant == 3 && !RT_PACK_HITS)) && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26)))
+    variant = variant == 4 && RT_PACK_HITS ? 3 : 0;
   // the re-packing, streamed and resident-wave shapes keep the whole scene image in LDS; bigger scenes render as tiles
   if ((variant == 3 || variant == 2 || variant == 4) && !image_fits) variant = 0;
   // tiles whose sphere records do not fit a workgroup's default 64 KB of LDS scan them from global memory

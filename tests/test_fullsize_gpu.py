@@ -199,3 +199,29 @@ def test_rank0_assembly_of_a_tile_split_frame(device, world, strip):
                 peers.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
     assert np.array_equal(out, full)
     assert np.array_equal(out, assemble_rows(pieces, size[1], strip))  # the host-side mirror agrees
+
+
+def test_a_launch_of_more_than_2_to_the_26_pixels_keeps_the_re_packing_shape(device):
+    """40 frames of 1920x1080 in one launch are 83 M pixels: the re-packing shape used to keep 26 bits of pixel index in its
+    exchange record and fell back to plain tiles beyond 67 M.  Same texels as five launches of eight frames."""
+    scene = cases.headline_scene(8)
+    size = (1920, 1080)
+    jit = synth.jitter_sequence(7, 40)
+    device.set_partition(0, 1, 8)
+    device.set_accum_mode(N.RT_ACCUM_SRGB8)
+    device.set_outputs(N.RT_OUT_RGBA8)
+    device.set_variant(-1)
+    rt = RandomTexture(device)
+    rt.write(synth.random_texture(1))
+    sums = []
+    for per_launch in (40, 8):
+        target = RenderTarget.new(device, size)
+        conn = Connection(scene, device, sky(), rt, max_objects="live")
+        conn.update_buffers(size, scene, (0.0, 0.0))
+        for k in range(0, 40, per_launch):
+            conn.draw_frames(jit[k:k + per_launch], k)
+        device.sync()
+        st = device.stats()
+        assert st.last_variant == 3 and st.last_batch == per_launch
+        sums.append(crc(target.read_rgba8()))
+    assert sums[0] == sums[1]
