@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """rt355 benchmark — BASELINE.json metric: Mrays/s at 1920x1080, 64 spheres, 8 bounces.
 
-A step is one 1-spp frame of BASELINE config 2 through the C-ABI: 64 spheres + the ground plane (65 live
-objects), 2048x1024 RGBA32F skybox, 600x600 random texture, everything resident in HBM before the timed
-region.  The frames are the progressive accumulation of a resting camera (frame k has progressive_count k,
-app.rs:208-254 / connection.rs:386-388).  A ray = one executed iteration of the bounce loop
-(frag.hlsl:36-43).  N GPUs split every frame into row strips and gather the sRGB8 texels on rank 0.
+A step is one pass of the hot path over one batch of synthetic input: ONE LAUNCH of 8 x N consecutive 1-spp frames of
+BASELINE config 2 through the C-ABI (rt_render_frames) on N GPUs — 64 spheres + the ground plane (65 live objects),
+2048x1024 RGBA32F skybox, 600x600 random texture, everything resident in HBM before the timed region.  The frames are
+the progressive accumulation of a resting camera (frame k has progressive_count k, app.rs:208-254 /
+connection.rs:386-388).  A ray = one executed iteration of the bounce loop (frag.hlsl:36-43).  N GPUs split every
+frame into row strips and gather the sRGB8 texels on rank 0 after every launch, so a step gives every GPU eight frames'
+worth of pixels whatever N is ("scaling": "weak"); `config.frames_per_step` says how many frames a step carried.
+(Until round 2 a step was one frame and a block of --steps 20 at N = 8 one launch of 20 eighth-frames: a third of a
+millisecond between two barriers.  `config.block_of_frames` still reports that protocol.)
 
 Protocol: an untimed clock warm-up of >= 2 s of back-to-back launches (on top of the
 --warmup steps), then the block of EXACTLY --steps steps — bracketed by barrier + synchronize on both sides,
 MAX over ranks — is repeated until >= 1 s has been measured and the MEDIAN block is reported
 (`steps`, `ms_per_step` keep their meaning: ms_per_step = median block / steps).
 
-`value` is the headline leg: 8 frames per launch per GPU (rt_render_frames; up to 16 where that divides --steps).  The same JSON line always
-carries, under `config`, the one-frame-per-launch leg (the reference's call pattern: one draw per loop turn)
-and the reference-exact 80-slot leg (15 zero-padded objects scanned as the reference's shader does).
+`value` is the headline leg: 8 frames per launch per GPU.  The same JSON line always carries, under `config`, the
+one-frame-per-launch leg (the reference's call pattern: one draw per loop turn; there a step is one frame) and the
+reference-exact 80-slot leg (15 zero-padded objects scanned as the reference's shader does).
 
 `roofline` prices the render kernel's ALGORITHMIC bytes (8 B/pixel + 16 B/segment +
 8 B/rough hit) against the 8 TB/s HBM peak, from per-launch HIP-event durations taken on the context's stream
@@ -238,9 +242,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return bool(t.item() > 0.5)
 
-    def timed_leg(B, steps, warm_steps, min_seconds, clock_warmup):
-        """Clock warm-up, `warm_steps` untimed steps, then blocks of exactly `steps` steps until min_seconds
-        have been measured.  Returns the per-block records; the caller reports the median block."""
+    def timed_leg(B, steps, warm_steps, min_seconds, clock_warmup, frames_per_block=None):
+        """Clock warm-up, `warm_steps` untimed steps, then blocks of exactly `steps` steps — a step = one launch of B
+        frames — until min_seconds have been measured.  Returns the per-block records; the caller reports the median
+        block.  `frames_per_block`: the round-2 protocol instead, a block = that many FRAMES, B per launch."""
         first = 0
         t_end = time.perf_counter() + clock_warmup
         while True:  # untimed: back-to-back launches so the clock has settled (DVFS) before anything is timed
@@ -249,7 +254,8 @@ def main():
             dev.sync()
             if not agree(time.perf_counter() < t_end):
                 break
-        warm = -(-warm_steps // B) * B  # whole launches, so every launch a profiler sees has the timed shape
+        block_frames = steps * B if frames_per_block is None else frames_per_block
+        warm = warm_steps * B  # whole launches, so every launch a profiler sees has the timed shape
         if warm:
             run_frames(first, warm, B)
             first += warm
@@ -257,7 +263,7 @@ def main():
         blocks, measured = [], 0.0
         while True:
             t0 = time.perf_counter()
-            launches = run_frames(first, steps, B)
+            launches = run_frames(first, block_frames, B)
             fence()
             dt = time.perf_counter() - t0
             seg = np.zeros(launches, np.uint64)
@@ -272,7 +278,7 @@ def main():
             # device time of the block's render kernels: the sum of their HIP-event times — or, when launches overlap
             # (several in flight), the span from the first kernel's start to the last one's end, which counts the
             # device once
-            blocks.append({"dt": dt, "launches": launches, "seg": float(seg.sum()), "rough": float(rough.sum()),
+            blocks.append({"dt": dt, "launches": launches, "frames": block_frames, "seg": float(seg.sum()), "rough": float(rough.sum()),
                            "kernel_ms": min(float(kms.sum()), float(span.value)), "kernel_ms_sum": float(kms.sum()),
                            "span_ms": float(span.value), "resolve_ms": float(rms.sum()), "first": first,
                            "seg_first_launch": int(seg[0])})
@@ -299,38 +305,38 @@ def main():
                 "dt_min": float(dts.min()), "dt_max": float(dts.max()), "measured_s": float(dts.sum())}
 
     # ---- headline leg: B frames per launch ------------------------------------------------------------------
-    # frames per launch: 8 per GPU of the job — or the next count up to 16 per GPU that divides --steps, so that a block
-    # of --steps frames has no ragged last launch (--steps 20: 10 frames per launch instead of 8 + 8 + 4)
+    # frames per launch = frames per step: 8 per GPU of the job (64 is the most one launch takes)
     B = args.batch
     if B <= 0:
         B = min(64, 8 * world)
-        for per_gpu in range(8, 17):
-            if per_gpu * world <= 64 and args.steps % (per_gpu * world) == 0:
-                B = per_gpu * world
-                break
     head = reduce_leg(timed_leg(B, args.steps, args.warmup, args.min_seconds, args.clock_warmup))
 
     # ---- extra legs: one frame per launch (reference call pattern); 80 zero-padded slots ------------------
     def leg_summary(leg, frames_per_launch):
         blk = leg["block"]
         return {"frames_per_launch": frames_per_launch, "launches_in_flight": 4 if frames_per_launch == 1 else args.batch_inflight,
-                "steps": args.steps,
+                "steps": args.steps, "frames_per_block": blk["frames"],
                 "ms_per_step": round(leg["elapsed"] / args.steps * 1e3, 5),
                 "mrays_per_s": round(leg["total_seg"] / leg["elapsed"] / 1e6, 2),
                 "kernel_mrays_per_s": round(blk["seg"] / (blk["kernel_ms"] * 1e-3) / 1e6, 2) if blk["kernel_ms"] else None,
                 "kernel": kernel_name(leg["stats"]), "blocks_timed": leg["n_blocks"]}
 
-    single = slots80 = None
+    single = slots80 = block_of_frames = None
     if not args.no_extra_legs:
         if B > 1:
             single = leg_summary(reduce_leg(timed_leg(1, args.steps, 8, args.min_seconds / 2, 0.25)), 1)
+            # the protocol of rounds 1-2: a block = --steps FRAMES (B per launch), i.e. a few launches between two barriers
+            old = reduce_leg(timed_leg(B, args.steps, 2, args.min_seconds / 4, 0.1, frames_per_block=args.steps))
+            block_of_frames = {"frames_per_block": args.steps, "launches_per_block": old["block"]["launches"],
+                               "ms_per_block": round(old["elapsed"] * 1e3, 5),
+                               "mrays_per_s": round(old["total_seg"] / old["elapsed"] / 1e6, 2)}
         if world == 1 and args.slots == 0 and len(scene.objects) <= 80:
             conn.max_objects = 80      # connection.rs: the fixed 80-slot buffer, zero-filled tail (scene.rs:28)
             conn.last_size = (0, 0)    # force the dirty branch of update_buffers
             conn.update_buffers((W, H), scene, (0.0, 0.0))
             leg80 = reduce_leg(timed_leg(B, args.steps, 8, args.min_seconds / 2, 0.25))
             slots80 = leg_summary(leg80, B)
-            f80 = algorithmic_flops(leg80["frame_px"] * args.steps, leg80["block"]["seg"], 80)
+            f80 = algorithmic_flops(leg80["frame_px"] * leg80["block"]["frames"], leg80["block"]["seg"], 80)
             slots80["valu_frac"] = round(f80 / (leg80["block"]["kernel_ms"] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 5)
             conn.max_objects = "live"
             conn.last_size = (0, 0)
@@ -369,13 +375,14 @@ def main():
 
     steps = args.steps
     elapsed, blk = head["elapsed"], head["block"]
+    n_frames = blk["frames"]  # of the median block: steps x B
     n_objects = len(scene.objects) if args.slots == 0 else args.slots
     value = head["total_seg"] / elapsed / 1e6
     # roofline of the dominant kernel (the render kernel), rank 0's launches of the median block
     launches = blk["launches"]
     k_sec = blk["kernel_ms"] * 1e-3
-    b_alg = algorithmic_bytes(head["frame_px"] * steps, blk["seg"], blk["rough"])
-    f_alg = algorithmic_flops(head["frame_px"] * steps, blk["seg"], n_objects)
+    b_alg = algorithmic_bytes(head["frame_px"] * n_frames, blk["seg"], blk["rough"])
+    f_alg = algorithmic_flops(head["frame_px"] * n_frames, blk["seg"], n_objects)
     achieved = b_alg / k_sec / 1e9
     # Measured HBM traffic and issue utilisation are IMPORTED from the committed PMC passes (separate rocprofv3 --pmc
     # runs cannot happen inside this process): quoted only when the profile was collected on THIS workload, this launch
@@ -404,7 +411,7 @@ def main():
                                      % (str(prof.get("kernel_source_sha256"))[:12], source_now[:12])}
             continue
         # per launch of THIS run: the profile's bytes per frame x the frames an average launch of the block carried
-        frames_per_launch = float(steps) / launches
+        frames_per_launch = float(n_frames) / launches
         per_frame = prof.get("render_kernel", {}).get("hbm_bytes_per_frame")
         traffic = round(per_frame * frames_per_launch, 1) if per_frame else None
         per_frame = prof.get("resolve_kernel", {}).get("hbm_bytes_per_frame")
@@ -422,7 +429,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 5),
         "higher_is_better": True,
-        "scaling": "strong",  # the frame size is fixed; every GPU renders 1/N of each frame's rows
+        "scaling": "weak",  # a step is 8 x N frames, each split over the N GPUs: eight frames' worth of pixels per GPU and step
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -433,18 +440,22 @@ def main():
                 args.strip_rows, world, ", strips gathered on rank 0 after every launch, beside the next one" if world > 1 else ""),
             "gather": gather_path,
             "gather_check": gather_check,
+            "step": "one launch of %d consecutive frames of the accumulation (rt_render_frames), every frame tile-split over the %d "
+                    "GPU(s): %d frames' worth of pixels per GPU and step, one gather per step" % (B, world, B // world),
+            "frames_per_step": B,
             "headline_mode": "%d consecutive frames of the accumulation per launch (%d per GPU), one gather per launch; the "
                              "one_frame_per_launch leg is the per-frame figure (one launch and one gather per frame)" % (B, B // world),
             "kernel_variant": args.variant,
             "frames_per_launch": B,
             "progressive_count": "frame index k (1-spp frames of a resting camera accumulate, app.rs:208-254)",
-            "timing": "median of %d blocks of %d steps (%.2f s measured, block %.3f..%.3f ms) after %.1f s of untimed "
-                      "launches + %d warm-up steps" % (head["n_blocks"], steps, head["measured_s"], head["dt_min"] * 1e3,
+            "timing": "median of %d blocks of %d steps = %d frames (%.2f s measured, block %.3f..%.3f ms) after %.1f s of untimed "
+                      "launches + %d warm-up steps" % (head["n_blocks"], steps, n_frames, head["measured_s"], head["dt_min"] * 1e3,
                                                       head["dt_max"] * 1e3, args.clock_warmup, args.warmup),
             "one_frame_per_launch": single,
             "reference_80_slots": slots80,
-            "segments_per_pixel": round(head["total_seg"] / (float(W) * H * steps), 4),
-            "mpixels_per_s": round(W * H * steps / elapsed / 1e6, 2),
+            "block_of_frames": block_of_frames,
+            "segments_per_pixel": round(head["total_seg"] / (float(W) * H * n_frames), 4),
+            "mpixels_per_s": round(W * H * n_frames / elapsed / 1e6, 2),
         },
         "roofline": {
             "bound": "hbm",
@@ -501,7 +512,7 @@ def main():
         oracle.render(objects, count, cfg, jit[k0 % n_jit], 0, sky, rnd, rows=(rows[0], rows[0] + 8),
                       threads=threads, want_hits=False)  # warm the thread pool
         cseg, cdt, frames, first_seg = 0, 0.0, 0, 0
-        first_n = min(B, steps)
+        first_n = B
         while (cdt < 12.0 or frames < first_n) and frames < 512:  # bounded sample: ~12 s of whole frames
             k = k0 + frames
             c0 = time.perf_counter()

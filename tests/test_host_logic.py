@@ -174,7 +174,11 @@ def test_committed_bench_line_keeps_the_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"] is None or r["traffic"] > 0
     # value = segments / time: consistent with ms_per_step and the segments per pixel the line reports
     px = 1920 * 1080
-    assert abs(d["value"] - d["config"]["segments_per_pixel"] * px / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    # a step is one launch of config.frames_per_step frames (8 per GPU)
+    per_step = d["config"]["frames_per_step"]
+    assert per_step == 8 * d["n_gpus"] and d["scaling"] == "weak"
+    assert abs(d["value"] - d["config"]["segments_per_pixel"] * px * per_step / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    assert d["config"]["block_of_frames"]["frames_per_block"] == d["steps"]  # the protocol of rounds 1-2, still reported
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
     assert 0.0 < d["valu"]["frac"] < 1.0 and d["valu"]["peak"] == 157.3
