@@ -30,21 +30,28 @@ for sky_w in (2048, 8192):
         conn = Connection(scene, dev, sky, rt, max_objects="live")
         conn.update_buffers((W, H), scene, (0.0, 0.0))
         dev.sync()
-        t0 = time.perf_counter()
-        for k in range(FRAMES):
-            if k % 8 == 0:
-                rt.generate_on_device()          # the reference refreshes the texture every ~4 ms
-            conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
-            conn.frame_data.progressive_count = k
-            conn.draw()
-        dev.sync()
-        dt = time.perf_counter() - t0
-        seg = np.zeros(FRAMES, np.uint64)
-        kms = np.zeros(FRAMES, np.float32)
-        dev.call("rt_get_frame_history", FRAMES, seg.ctypes.data_as(C.c_void_p), None, kms.ctypes.data_as(C.c_void_p))
-        span = C.c_float(0.0)  # the launches overlap (four in flight): device time = first kernel's start .. last one's end
-        dev.call("rt_get_launch_span", FRAMES, C.byref(span))
-        print("skybox %dx%d (%d MiB), %s: %d frames in %.1f ms = %.0f fps, %.1f Grays/s wall, %.1f Grays/s over the render kernels' span"
-              % (sky_w, sky_w // 2, sky_w * sky_w // 2 * 16 >> 20, name, FRAMES, dt * 1e3, FRAMES / dt,
-                 seg.sum() / dt / 1e9, seg.sum() / (span.value * 1e-3) / 1e9), flush=True)
+        for per_launch in (1, 8):  # the reference's loop turn by turn, and the same 256 frames eight per launch
+            conn.frame_data.progressive_count = 0
+            dev.sync()
+            t0 = time.perf_counter()
+            for k in range(0, FRAMES, per_launch):
+                if k % 8 == 0:
+                    rt.generate_on_device()          # the reference refreshes the texture every ~4 ms
+                if per_launch == 1:
+                    conn.frame_data.jitter = (float(jit[k, 0]), float(jit[k, 1]))
+                    conn.frame_data.progressive_count = k
+                    conn.draw()
+                else:
+                    conn.draw_frames(jit[k:k + per_launch], k)
+            dev.sync()
+            dt = time.perf_counter() - t0
+            launches = FRAMES // per_launch
+            seg = np.zeros(launches, np.uint64)
+            kms = np.zeros(launches, np.float32)
+            dev.call("rt_get_frame_history", launches, seg.ctypes.data_as(C.c_void_p), None, kms.ctypes.data_as(C.c_void_p))
+            span = C.c_float(0.0)  # launches may overlap (four single frames in flight): device time = first kernel's start .. last one's end
+            dev.call("rt_get_launch_span", launches, C.byref(span))
+            print("skybox %dx%d (%d MiB), %s, %d frame(s) per launch: %d frames in %.1f ms = %.0f fps, %.1f Grays/s wall, %.1f Grays/s over the "
+                  "render kernels' span" % (sky_w, sky_w // 2, sky_w * sky_w // 2 * 16 >> 20, name, per_launch, FRAMES, dt * 1e3, FRAMES / dt,
+                                            seg.sum() / dt / 1e9, seg.sum() / (span.value * 1e-3) / 1e9), flush=True)
     del sky
