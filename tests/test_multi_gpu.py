@@ -161,3 +161,34 @@ def test_random_texture_thread_never_splits_a_frame_between_two_textures():
         assert not errors and min(seen) > 0
     finally:
         dev.close()
+
+
+def test_more_devices_than_strips():
+    """A 20-row frame has three strips of 8 rows: of eight members five own nothing — they launch nothing, send nothing, and
+    the frame is still the oracle's."""
+    scene = cases.headline_scene(3)
+    size = (64, 20)
+    sky, rnd = cases.inputs(64, 32)
+    dev = MultiDevice([0] * 8, 8)
+    try:
+        RenderTarget.new(dev, size)
+        rt = RandomTexture(dev)
+        rt.write(rnd)
+        conn = Connection(scene, dev, sky, rt, max_objects="live")
+        conn.update_buffers(size, scene, (0.0, 0.0))
+        jit = synth.jitter_sequence(4, 4)
+        want = oracle_chain(scene, size, sky, rnd, jit, 0, 0)
+        conn.frame_data.jitter, conn.frame_data.progressive_count = (float(jit[0, 0]), float(jit[0, 1])), 0
+        conn.draw()
+        assert np.array_equal(dev.read_frame_rgba8(*size), want[0].rgba8)
+        conn.draw_frames(jit[1:4], 1)
+        assert np.array_equal(dev.read_frame_rgba8(*size), want[3].rgba8)
+        lib = N.load()
+        rows = []
+        for i in range(8):
+            st = N.RtStats()
+            assert lib.rt_get_stats(dev.member(i), C.byref(st)) == 0
+            rows.append(st.local_rows)
+        assert rows == [8, 8, 4, 0, 0, 0, 0, 0]
+    finally:
+        dev.close()
