@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import oracle  # noqa: E402
-from rsraytracingv3_amd import Connection, Device, RandomTexture, RenderTarget, render_scene, synth  # noqa: E402
+from rsraytracingv3_amd import Connection, Device, MultiDevice, RandomTexture, RenderTarget, render_scene, synth  # noqa: E402
 from rsraytracingv3_amd import _native as N  # noqa: E402
 from rsraytracingv3_amd.scene import Camera, Geometry, Material, Object, Scene  # noqa: E402
 
@@ -60,8 +60,9 @@ def dirmask_for(seed):
 
 def run(cases=100, first=0):
     dev = Device(0)
+    multi = MultiDevice([0, 0, 0], 8)  # every seventh case also goes through three contexts of one process (rt_multi_*)
     sky = synth.procedural_skybox(128, 64)
-    bad = grids = tables = 0
+    bad = grids = tables = multis = 0
     for seed in range(first, first + cases):
         scene, size, jitter, slots, variant, tex_seed = random_case(seed)
         rnd = synth.random_texture(tex_seed)
@@ -111,6 +112,23 @@ def run(cases=100, first=0):
                   and np.array_equal(target.read_rgbf32().view(np.uint32), ref.rgbf32.view(np.uint32)))
             if not ok:
                 print("  (in the %d-frame launch, first count %d, accum %d)" % (nf, pc0, accum), flush=True)
+        if ok and seed % 7 == 3:  # the same frame, its row strips dealt over three contexts and gathered on the first
+            multis += 1
+            for opt, val in dirmask_for(seed).items():
+                multi.set_option(opt, val)
+            multi.set_option(N.RT_OPT_GRID_MIN, grid_min_for(seed))
+            multi.set_accum_mode(N.RT_ACCUM_SRGB8)
+            RenderTarget.new(multi, size)
+            rtm = RandomTexture(multi)
+            rtm.write(rnd)
+            connm = Connection(scene, multi, sky, rtm, max_objects=slots)
+            connm.update_buffers(size, scene, jitter)
+            connm.frame_data.jitter, connm.frame_data.progressive_count = jitter, 0
+            connm.draw()
+            first_ref = oracle.render(objects, count, scene.config_bytes(w, h), jitter, 0, sky, rnd, threads=8, want_hits=False)
+            ok = np.array_equal(multi.read_frame_rgba8(w, h), first_ref.rgba8)
+            if not ok:
+                print("  (through the three-context rt_multi)", flush=True)
         if not ok:
             bad += 1
             print("MISMATCH seed %d: %d objects, size %s, R %d, variant %d, slots %s, cull mismatches %d, grid cells %d, mask table %d x %d"
@@ -124,8 +142,9 @@ def run(cases=100, first=0):
     dev.set_option(N.RT_OPT_CULL, 1)
     dev.set_option(N.RT_OPT_GRID_MIN, 129)
     dev.close()
-    print("fuzz: %d cases from seed %d (%d of them walked a sphere grid, %d used a direction-mask table), %d mismatching"
-          % (cases, first, grids, tables, bad), flush=True)
+    multi.close()
+    print("fuzz: %d cases from seed %d (%d of them walked a sphere grid, %d used a direction-mask table, %d also went through a "
+          "three-context rt_multi), %d mismatching" % (cases, first, grids, tables, multis, bad), flush=True)
     return bad
 
 
