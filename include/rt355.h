@@ -327,6 +327,10 @@ enum {
   RT_OPT_DIRMASK_MIN = 10,  /* fewest spheres that get the table (default 26)                                            */
   RT_OPT_DIRMASK_CELLS = 11,/* cells the table's grid aims at (default 4096; cubic cells, at most 64 per axis)           */
   RT_OPT_DIRMASK_K = 12,    /* direction bins per cube-map face edge, 1..16 (default 12: 864 bins)                       */
+  RT_OPT_TAIL_SPILL = 13,   /* multi-frame launches of the re-packing shape on a scene with a direction-mask table: a workgroup
+                             * whose paths that hit number at most this many (0..128; 0 = off) hands them to a path queue in
+                             * device memory and ends; a second kernel takes them up into full waves for their remaining bounces
+                             * (bit-identical; the queue takes 80 B per path, at most workgroups x threshold of them)          */
   RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 1): as RT_OPT_INFLIGHT,
                               each launch staging its samples in a buffer of its own; the history is updated in frame
                               order on the context's stream.  2 hides the resolve pass and the gap between launches

@@ -142,6 +142,11 @@ struct FrameParams {
   float4 *queue;
   uint32_t queue_shard_cap;
   size_t queue_plane;
+  // Tail spill of the re-packing shape (variant 3, multi-frame launches; tail_stream in rt_kernels.hip): a workgroup whose
+  // paths that hit number at most spill_max appends them — path state + hit, 80 B as five planes of the same queue — and
+  // ends; tail_stream shades and continues them in full waves.  0 = off.  A workgroup spills once, so a shard of
+  // ceil(workgroups / kQueueShards) * spill_max records cannot overflow (tail_spill_plan).
+  uint32_t spill_max;
 };
 
 // resolve_batch_kernel: folds a batch's float samples into the history, frame by frame
@@ -174,6 +179,7 @@ struct LaunchConfig {
   int tile_chunk;         // variant 2: consecutive 8x8 tiles per counter increment; variant 4: 64-path units a wave
                           // takes off the queue per counter increment
   int stream_blocks;      // variant 4: grid size of the bounce pass (resident workgroups)
+  int tail_blocks;        // variant 3 with a tail spill (FrameParams::spill_max): grid size of tail_stream (resident workgroups)
   int flags;              // reserved for experiment switches
 };
 int persistent_blocks_per_cu(size_t lds_bytes);
@@ -184,6 +190,13 @@ int prof_counts(unsigned long long out8[8], bool reset);
 int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc);
 uint32_t stream_queue_shard_cap(const FrameParams &fp);
 int stream_blocks_per_cu(size_t lds_bytes);
+// Tail spill (FrameParams::spill_max): the threshold this launch would run with when `wanted` is asked for (0: the launch
+// shape, the scene or the queue budget rule it out) and the records per queue shard it needs (five float4 planes of
+// kQueueShards shards); resident workgroups per CU of tail_stream.
+constexpr int kDefaultTailSpill = 0;           // RT_OPT_TAIL_SPILL
+constexpr size_t kTailQueueBudget = 4ull << 30;  // bytes of queue a launch may ask for; the threshold shrinks to fit
+uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap);
+int tail_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);
 int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream);
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream,

@@ -1238,7 +1238,7 @@ __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FramePar
 // most of a tile's later scans run with a handful of live lanes.  Pixel results do not depend on which
 // lane finishes a path, so the frame stays bit-identical.  (RT_PACK_HITS 0: count and pack the survivors after
 // the shading instead.)
-template <int NW, int WAVES, bool LEAN>
+template <int NW, int WAVES, bool LEAN, bool SPILL = false>
 __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_all[];
   // The single-frame form (WAVES = 5) overlaps with its neighbours' launches and runs best at 5 waves per SIMD (A/B on
@@ -1315,6 +1315,31 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
       total += c;
     }
     if (total == 0u) break;
+    if (SPILL && total <= fp.spill_max && iters < fp.reflection_limit) {
+      // Tail spill: so few paths are left that the rest of their bounces would run in a mostly empty wave.  They go — path
+      // state + hit, the record of the exchange buffer — to the launch's path queue, where tail_stream picks them up into
+      // full waves, and the workgroup ends.  (When only the last shading is left, iters == reflection_limit, it is done here.)
+      if (live != 0ull) {  // wave-uniform
+        const uint32_t shard = linear_block() % kQueueShards;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&fp.tile_counters[shard * 32u], static_cast<uint32_t>(__popcll(live)));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (alive) {
+          const size_t r = static_cast<size_t>(shard) * fp.queue_shard_cap + base +
+                           __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
+          float4 *q = fp.queue + r;
+          q[0] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
+          q[fp.queue_plane] = make_float4(s.d.y, s.d.z, s.energy.x, s.energy.y);
+          q[2 * fp.queue_plane] = make_float4(s.energy.z, s.result.x, s.result.y, s.result.z);
+          q[3 * fp.queue_plane] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p));
+          q[4 * fp.queue_plane] = make_float4(h.t, __int_as_float(h.slot), __int_as_float(h.obj),
+                                              __uint_as_float((h.plane ? 1u : 0u) | (s.seg << 1)));
+          alive = false;  // not finished: the path goes on elsewhere
+        }
+      }
+      break;
+    }
     const uint32_t need = (total + 63u) >> 6;
     if (need < live_waves && total <= kXchgPaths) {
       // pack: path number = paths in lower waves + live lanes below this one; the hit travels with the path
@@ -1450,7 +1475,9 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
     if (rough_total) atomicAdd(&shard[1], static_cast<unsigned long long>(rough_total));
     atomicAdd(&shard[2], static_cast<unsigned long long>(iters));
   }
+#ifndef RT_PH_TAIL_ONLY  // (diagnostic build of tail_stream's stamps alone)
   RT_PH_FLUSH(fp.counters + static_cast<size_t>(linear_block() % kTotalShards) * kTotalShardStride)
+#endif
 }
 
 // Streamed shape (variant 4), for launches of several frames that write float samples only.  Two kernels:
@@ -1626,6 +1653,157 @@ __global__ void __launch_bounds__(NW * 64, WAVES) bounce_stream(DeviceScene sc, 
       seg_total += s.seg;
     }
     RT_PH_MARK(6)
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    seg_total += __shfl_xor(seg_total, off, 64);
+    rough_total += __shfl_xor(rough_total, off, 64);
+  }
+  if (lane == 0) {
+    unsigned long long *shard_totals = fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride;
+    if (seg_total) atomicAdd(&shard_totals[0], static_cast<unsigned long long>(seg_total));
+    if (rough_total) atomicAdd(&shard_totals[1], static_cast<unsigned long long>(rough_total));
+    if (wave_iters) atomicAdd(&shard_totals[2], static_cast<unsigned long long>(wave_iters));
+  }
+  RT_PH_FLUSH(fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride)
+}
+
+// Tail of the re-packing shape (FrameParams::spill_max): render_blocks' workgroups hand the last few paths of their tiles —
+// the ones that would otherwise bounce on in a mostly empty wave, each with the hit its scan has just found — to the path
+// queue; resident waves here take them off it in chunks, SHADE them (every lane that carries a path carries a pending hit),
+// scan the survivors' next segment, and refill the lanes whose path has ended.  The expensive half of an iteration, the
+// shading, therefore runs with full waves until the queue is dry.  Pixel results do not depend on which lane carries a
+// path, so the frame stays bit-identical.  Runs after render_blocks on the same stream: the write heads are final.
+#ifndef RT_TAIL_NW
+#define RT_TAIL_NW 2  // waves per workgroup (they share the staged scene image only)
+#endif
+#ifndef RT_TAIL_WAVES
+#define RT_TAIL_WAVES 5  // waves per SIMD tail_stream is budgeted for (96 registers, no scratch; 6: 52 B, 7: 92 B of scratch per lane —
+                         // A/B on one device at threshold 32: 53.0 / 51.8 / 49.3 Grays/s)
+#endif
+template <int NW, int WAVES>
+__global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, FrameParams fp, uint32_t refill_min, uint32_t chunk) {
+  extern __shared__ float4 lds_all[];
+  for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
+  __syncthreads();
+  const SceneView sv = make_view(sc, lds_all, lds_all);
+  unsigned char *scratch = reinterpret_cast<unsigned char *>(lds_all + sc.image_records);  // NW x kScanScratchBytes
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  // Every wave draws on ONE shard of the queue, its own: the workgroups of render_blocks append to the shards in turn and
+  // the waves here are dealt over them evenly, so the shards run dry together — and a wave learns that it is done from one
+  // failed bump of one counter.  (Looking into the other shards as well — one by one, all at once, or only when the own one
+  // is dry — costs each of the ~5 000 waves a visit to each of the 32 busy lines at the end, and a line serves ~90 visits
+  // per microsecond: 30 - 170 microseconds per launch, measured: profiles/r03_tail_spill.txt.)
+  const uint32_t shard = (blockIdx.x * NW + wave) % kQueueShards;
+  const uint32_t own_filled = fp.tile_counters[shard * 32u];  // final: render_blocks ran before this kernel
+  bool own_dry = own_filled == 0u;
+  size_t q_pos = 0, q_end = 0;  // records of the chunk in hand [q_pos, q_end), absolute record numbers
+  Path s;
+  s.p = 0;
+  s.seg = 0;
+  s.rough = 0;
+  s.o = s.d = s.energy = s.result = mk3(0.0f, 0.0f, 0.0f);
+  s.rng = Rng{0.0f, 0.0f, 0.0f};
+  Hit h;
+  h.t = 0.0f;
+  h.obj = -1;
+  h.slot = -1;
+  h.plane = false;
+  bool alive = false;     // the lane carries a path whose hit `h` is to be shaded
+  bool finished = false;  // the lane holds the result of a path that has ended (written out before the lane is re-used)
+  bool work_left = true;
+  uint32_t seg_total = 0, rough_total = 0, wave_iters = 0;
+  RT_PH_DECL
+  for (;;) {
+    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!alive);
+    const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
+    if (work_left && n_idle >= refill_min) {
+      if (finished) {  // the lane's registers are about to change hands
+        path_end<RT_DEFER_SKY_BLOCKS, true>(fp, s);
+        seg_total += s.seg;
+        finished = false;
+      }
+      RT_PH_MARK(7)
+      unsigned long long need = idle;
+      while (need != 0ull) {
+        if (q_pos >= q_end) {  // next chunk
+          bool got = false;
+          if (!own_dry) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(&fp.tile_counters[(kQueueShards + shard) * 32u], chunk);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t < own_filled) {
+              q_pos = static_cast<size_t>(shard) * fp.queue_shard_cap + t;
+              q_end = q_pos + min(chunk, own_filled - t);
+              got = true;
+            } else {
+              own_dry = true;
+            }
+          }
+          RT_PH_MARK(4)
+          if (!got) {
+            work_left = false;
+            break;
+          }
+        }
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(need >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(need), 0u));
+        const bool needy = (need >> lane) & 1ull;
+        const uint32_t n_need = static_cast<uint32_t>(__popcll(need));
+        const uint32_t room = static_cast<uint32_t>(q_end - q_pos);
+        const uint32_t taken = n_need < room ? n_need : room;
+        if (needy && below < taken) {
+          const float4 *q = fp.queue + q_pos + below;
+          const float4 a = q[0], b = q[fp.queue_plane], c = q[2 * fp.queue_plane], e = q[3 * fp.queue_plane],
+                       g = q[4 * fp.queue_plane];
+          s.o = mk3(a.x, a.y, a.z);
+          s.d = mk3(a.w, b.x, b.y);
+          s.energy = mk3(b.z, b.w, c.x);
+          s.result = mk3(c.y, c.z, c.w);
+          s.rng = Rng{e.x, e.y, e.z};
+          s.p = __float_as_uint(e.w);
+          s.seg = __float_as_uint(g.w) >> 1;
+          s.rough = 0;
+          h.t = g.x;
+          h.slot = __float_as_int(g.y);
+          h.obj = __float_as_int(g.z);
+          h.plane = (__float_as_uint(g.w) & 1u) != 0u;
+          alive = true;
+        }
+        q_pos += taken;
+        need = __builtin_amdgcn_ballot_w64(needy && below >= taken);
+      }
+    }
+    RT_PH_MARK(5)
+#ifdef RT_PROFILE_PHASES  // how long the records take to arrive, apart from the shading
+    __builtin_amdgcn_s_waitcnt(0);
+    RT_PH_MARK(0)
+#endif
+    if (__builtin_amdgcn_ballot_w64(alive) == 0ull) {
+      if (!work_left) break;
+      continue;
+    }
+    wave_iters += 1u;
+    if (alive) {  // shade the pending hit (render_blocks' shading step)
+      const float x1 = fp.rnd[rng_texel(fp, s.rng)];
+      alive = path_shade<RT_DEFER_SKY_BLOCKS, true>(sv, fp, s, h, x1, 0.0f, 0.0f);
+      rough_total += s.rough & 0x7fffffffu;
+      s.rough &= 0x80000000u;
+      finished |= !alive;
+    }
+    RT_PH_MARK(3)
+    h = path_scan_wave<true>(sv, fp, s, alive, nullptr, nullptr, scratch RT_PH_ARGS);
+    if (alive && h.obj < 0) {  // frag.hlsl:14-17: a miss ends the path (its skybox texel is fetched in path_end)
+      (void)path_shade<RT_DEFER_SKY_BLOCKS, true>(sv, fp, s, h, 0.0f, 0.0f, 0.0f);
+      alive = false;
+      finished = true;
+    }
+    RT_PH_MARK(6)
+  }
+  if (finished) {
+    path_end<RT_DEFER_SKY_BLOCKS, true>(fp, s);
+    seg_total += s.seg;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -2050,12 +2228,26 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     const size_t bytes = lds_image + kBlocksLdsExtra;  // exchange buffer and the waves' scan scratch
     const bool lean = sample_only(fp);
     if (fp.batch > 1u && lean) {
+      const bool spill = fp.spill_max != 0u && fp.queue != nullptr;
       if (sc.dm.enabled && sc.dm.words > 1u) {
         if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH_WIDE;
-        hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH_WIDE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+        if (spill)
+          hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH_WIDE, true, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+        else
+          hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH_WIDE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
       } else {
         if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
-        hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+        if (spill)
+          hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+        else
+          hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      }
+      if (spill) {  // the spilled paths' remaining bounces, in full waves
+        if (stage_used) *stage_used += 100;
+        const uint32_t blocks2 = static_cast<uint32_t>(lc.tail_blocks < 1 ? 1 : lc.tail_blocks);
+        const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
+        hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES>), dim3(blocks2), dim3(RT_TAIL_NW * 64),
+                           lds_image + RT_TAIL_NW * kScanScratchBytes, stream, sc, fp, static_cast<uint32_t>(lc.refill_min), chunk);
       }
     } else if (lean) {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
@@ -2114,6 +2306,29 @@ int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n,
   hipLaunchKernelGGL(dirmask_build_kernel, dim3(static_cast<uint32_t>((entries + 256ull) / 256ull)), dim3(256), 0, stream, dm, reg, n,
                      table, entries);  // entries + 1 threads: the last writes the zero entry
   return static_cast<int>(hipGetLastError());
+}
+
+uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap) {
+  if (shard_cap) *shard_cap = 0;
+  // multi-frame sample-only launches of the re-packing shape whose secondary rays use the balanced scan (tail_stream has its scratch)
+  if (wanted == 0u || !RT_PACK_HITS || fp.batch < 2u || !sample_only(fp) || !sc.dm.enabled || pick_variant(sc, fp, lc) != 3) return 0u;
+  const uint32_t tiles_x = (fp.width + kTile - 1) / kTile, tiles_y = (fp.local_rows + kTile - 1) / kTile;
+  const uint64_t blocks = static_cast<uint64_t>((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW) * tiles_y * fp.batch;  // render_blocks' grid
+  const uint64_t per_shard = (blocks + kQueueShards - 1) / kQueueShards;  // workgroups that append to one shard, each once
+  uint64_t t = wanted > RT_BLOCK_NW * 64u ? RT_BLOCK_NW * 64u : wanted;
+  const uint64_t fit = kTailQueueBudget / (per_shard * kQueueShards * 5ull * sizeof(float4));
+  if (t > fit) t = fit;
+  if (t < 4u || per_shard * t > 0xffffffffull) return 0u;
+  if (shard_cap) *shard_cap = static_cast<uint32_t>(per_shard * t);
+  return static_cast<uint32_t>(t);
+}
+
+int tail_blocks_per_cu(size_t lds_bytes) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_stream<RT_TAIL_NW, RT_TAIL_WAVES>, RT_TAIL_NW * 64,
+                                                   lds_bytes + RT_TAIL_NW * kScanScratchBytes) != hipSuccess)
+    return 0;
+  return n;
 }
 
 int stream_blocks_per_cu(size_t lds_bytes) {

@@ -85,6 +85,9 @@ struct rt_context {
   int blocks_per_cu = 0;    // RT_OPT_BLOCKS_PER_CU (0 = occupancy query)
   int cu_count = 0;
   int tile_chunk = 2;       // RT_OPT_TILE_CHUNK
+  int tail_spill = kDefaultTailSpill;  // RT_OPT_TAIL_SPILL: a workgroup with at most this many paths left hands them to tail_stream
+  int tail_occupancy_blocks = 0;       // resident tail_stream workgroups per CU for tail_occupancy_records of scene image
+  uint32_t tail_occupancy_records = 0;
   int flags = 0;            // RT_OPT_FLAGS
   int cull = 1;             // RT_OPT_CULL: 0 off, 1 on, 2 on + self-check against the full scan
   unsigned long long *d_masks = nullptr;  // per-tile sphere masks of the primary-ray culling
@@ -1079,6 +1082,10 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       if (value < 1 || value > static_cast<int>(kDirMaskMaxK)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_DIRMASK_K takes 1..%u", kDirMaskMaxK);
       ctx->dirmask_k = value;
       return RT_OK;
+    case RT_OPT_TAIL_SPILL:
+      if (value < 0 || value > 128) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TAIL_SPILL takes 0..128");
+      ctx->tail_spill = value;
+      return RT_OK;
     case RT_OPT_BATCH_INFLIGHT:
       if (value < 1 || value > rt_context::kMaxInflight)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BATCH_INFLIGHT takes 1..%d", rt_context::kMaxInflight);
@@ -1381,6 +1388,41 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     }
     const int per_cu_stream = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->stream_occupancy_blocks > 0 ? ctx->stream_occupancy_blocks : 4);
     lc.stream_blocks = per_cu_stream * ctx->cu_count;
+  }
+  fp.spill_max = 0;
+  if (ctx->tail_spill > 0 && fp.queue == nullptr) {  // tail spill of the re-packing shape: needs the queue and tail_stream's grid
+    uint32_t shard_cap = 0;
+    const uint32_t t = tail_spill_plan(ctx->scene, fp, lc, static_cast<uint32_t>(ctx->tail_spill), &shard_cap);
+    if (t != 0u) {
+      const int qi = pipelined ? lane : static_cast<int>(rt_context::kMaxInflight);
+      const size_t plane = static_cast<size_t>(shard_cap) * kQueueShards;
+      bool have = ctx->queue_cap[qi] >= 5 * plane;
+      if (!have) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the main stream has waited for every render so far
+        (void)hipFree(ctx->d_queue[qi]);
+        ctx->d_queue[qi] = nullptr;
+        ctx->queue_cap[qi] = 0;
+        if (hipMalloc(&ctx->d_queue[qi], 5 * plane * sizeof(float4)) == hipSuccess) {
+          ctx->queue_cap[qi] = 5 * plane;
+          have = true;
+        } else {
+          (void)hipGetLastError();  // no memory for the queue: the launch runs without the spill
+          ctx->d_queue[qi] = nullptr;
+        }
+      }
+      if (have) {
+        fp.queue = ctx->d_queue[qi];
+        fp.queue_shard_cap = shard_cap;
+        fp.queue_plane = plane;
+        fp.spill_max = t;
+        if (ctx->tail_occupancy_records != ctx->scene.image_records || ctx->tail_occupancy_blocks == 0) {
+          ctx->tail_occupancy_blocks = tail_blocks_per_cu(static_cast<size_t>(ctx->scene.image_records) * sizeof(float4));
+          ctx->tail_occupancy_records = ctx->scene.image_records;
+        }
+        const int per_cu_tail = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->tail_occupancy_blocks > 0 ? ctx->tail_occupancy_blocks : 4);
+        lc.tail_blocks = per_cu_tail * ctx->cu_count;
+      }
+    }
   }
   RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], render_stream));
   int per_cu = ctx->blocks_per_cu;

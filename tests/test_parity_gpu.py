@@ -331,7 +331,7 @@ def test_device_math_bitwise(device):
         assert 0 <= i < 2048 and 0 <= j < 1024
 
 
-def _batch_vs_sequential(device, scene, size, sky, rnd, jitters, first_pc, accum, variant, partition=(0, 1, 8)):
+def _batch_vs_sequential(device, scene, size, sky, rnd, jitters, first_pc, accum, variant, partition=(0, 1, 8), max_objects="live"):
     """Renders len(jitters) frames once as separate launches and once as ONE rt_render_frames launch from the
     same starting history; returns the two (rgba8, rgbf32) states after the last frame plus the stats."""
     device.set_partition(*partition)
@@ -341,7 +341,7 @@ def _batch_vs_sequential(device, scene, size, sky, rnd, jitters, first_pc, accum
     target = RenderTarget.new(device, size)
     rt = RandomTexture(device)
     rt.write(rnd)
-    conn = Connection(scene, device, sky, rt, max_objects="live")
+    conn = Connection(scene, device, sky, rt, max_objects=max_objects)
     conn.update_buffers(size, scene, (0.0, 0.0))
     states = []
     for mode in ("sequential", "batch"):
@@ -397,6 +397,49 @@ def test_streamed_shape_primary_pass_queue_bounce_pass(device, refill_min, tile_
     finally:
         device.set_option(N.RT_OPT_REFILL_MIN, 1)
         device.set_option(N.RT_OPT_TILE_CHUNK, 2)
+
+
+@pytest.mark.parametrize("case", ["headline_live", "reference_80_slots", "mirrors", "rank_1_of_3"])
+def test_tail_spill_hands_the_last_paths_to_full_waves(device, case):
+    """RT_OPT_TAIL_SPILL: a workgroup of the re-packing shape with at most T paths left appends them, with their pending
+    hits, to the path queue, and tail_stream shades and continues them in refilled waves.  Texels, floats and the segment /
+    rough-hit totals of a multi-frame launch equal the sequential frames' for every threshold (4 = late bounces only ...
+    128 = everything after the primary scan), refill threshold and chunk size."""
+    from rsraytracingv3_amd.scene import Camera
+    size, slots, partition = (333, 187), "live", (0, 1, 8)
+    scene = cases.headline_scene(24)
+    if case == "reference_80_slots":   # 79 spheres: two-word candidate sets, the 6-wave instance
+        slots = None
+    elif case == "mirrors":            # long paths between smooth spheres: the tail runs most of the bounces
+        for o in scene.objects:
+            o.material.roughness = 0.0
+        scene.camera = Camera((30.0, 6.0, 30.0), (0.1, -2.3, 0.0), 75.0)
+    elif case == "rank_1_of_3":
+        size, partition = (250, 203), (1, 3, 8)
+    sky, rnd = cases.inputs(256, 128)
+    jit = [(0.1, -0.2), (-0.33, 0.27), (0.45, 0.05), (-0.49, -0.49), (0.0, 0.31), (0.2, 0.2)]
+    try:
+        device.set_option(N.RT_OPT_TAIL_SPILL, 0)
+        (seq, bat0), st0 = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 3, partition, slots)
+        assert st0.last_variant == 3 and st0.last_stage < 100 and st0.dirmask_cells > 0
+        assert np.array_equal(seq[0], bat0[0]) and np.array_equal(seq[1].view(np.uint32), bat0[1].view(np.uint32))
+        for t, refill_min, chunk in ((4, 1, 1), (24, 16, 2), (64, 9, 3), (128, 64, 1), (32, 1, 2)):
+            device.set_option(N.RT_OPT_TAIL_SPILL, t)
+            device.set_option(N.RT_OPT_REFILL_MIN, refill_min)
+            device.set_option(N.RT_OPT_TILE_CHUNK, chunk)
+            (_, bat), st = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 3, partition, slots)
+            assert st.last_variant == 3 and st.last_stage >= 100, "the launch did not take the spilling shape"
+            assert (st.last_segments, st.last_rough_hits) == (st0.last_segments, st0.last_rough_hits)
+            assert np.array_equal(seq[0], bat[0]), "threshold %d: texels differ" % t
+            assert np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32)), "threshold %d: floats differ" % t
+        # single-frame launches and scenes without a table never spill
+        outs, st1 = run_gpu(device, scene, (96, 64), sky, rnd, (0.0, 0.0), variant=3, max_objects=slots)
+        assert st1.last_stage < 100
+    finally:
+        device.set_option(N.RT_OPT_TAIL_SPILL, N.RT_TAIL_SPILL_DEFAULT)
+        device.set_option(N.RT_OPT_REFILL_MIN, 1)
+        device.set_option(N.RT_OPT_TILE_CHUNK, 2)
+        device.set_partition(0, 1, 8)
 
 
 def test_streamed_shape_under_a_partition_and_its_fall_back(device):

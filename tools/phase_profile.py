@@ -29,6 +29,8 @@ ap.add_argument("--variant", type=int, default=-1)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spheres", type=int, default=64)
+ap.add_argument("--tail-spill", type=int, default=-1, help="RT_OPT_TAIL_SPILL (tail_stream's stamps: 5 refill, 3 shading, 1 scan, 6 misses)")
+ap.add_argument("--refill-min", type=int, default=1)
 args = ap.parse_args()
 W, H = args.width, args.height
 scene = cases.headline_scene(8) if args.spheres == 64 else cases.stress_scene(args.spheres, 8)
@@ -37,6 +39,9 @@ dev.set_outputs(N.RT_OUT_RGBA8)
 dev.set_variant(args.variant)
 dev.set_option(N.RT_OPT_BATCH_INFLIGHT, 1)  # one launch at a time: the kernel time printed is one kernel's alone
 dev.set_option(N.RT_OPT_INFLIGHT, 1)
+if args.tail_spill >= 0:
+    dev.set_option(N.RT_OPT_TAIL_SPILL, args.tail_spill)
+dev.set_option(N.RT_OPT_REFILL_MIN, args.refill_min)
 target = RenderTarget.new(dev, (W, H))
 rt = RandomTexture(dev)
 rt.write(synth.random_texture(1))
