@@ -278,6 +278,8 @@ def main():
             dev.call("rt_get_frame_history", launches, seg.ctypes.data_as(C.c_void_p), rough.ctypes.data_as(C.c_void_p),
                      kms.ctypes.data_as(C.c_void_p))
             dev.call("rt_get_resolve_history", launches, rms.ctypes.data_as(C.c_void_p))
+            tms = np.zeros(launches, np.float32)
+            dev.call("rt_get_tail_history", launches, tms.ctypes.data_as(C.c_void_p))
             span = C.c_float(0.0)
             dev.call("rt_get_launch_span", launches, C.byref(span))
             # device time of the block's render kernels: the sum of their HIP-event times — or, when launches overlap
@@ -285,7 +287,7 @@ def main():
             # device once
             blocks.append({"dt": dt, "launches": launches, "frames": block_frames, "seg": float(seg.sum()), "rough": float(rough.sum()),
                            "kernel_ms": min(float(kms.sum()), float(span.value)), "kernel_ms_sum": float(kms.sum()),
-                           "span_ms": float(span.value), "resolve_ms": float(rms.sum()), "first": first,
+                           "span_ms": float(span.value), "resolve_ms": float(rms.sum()), "tail_ms": float(tms.sum()), "first": first,
                            "seg_first_launch": int(seg[0])})
             measured += dt
             if not agree(measured < min_seconds and len(blocks) < 4096):
@@ -482,7 +484,12 @@ def main():
                             "mean HIP-event duration of one kernel, which is what a kernel trace averages and includes the time "
                             "it shared the device with its neighbour; --batch-inflight 1 gives non-overlapping kernels"
                             % args.batch_inflight) if (B > 1 and args.batch_inflight > 1) else
-                           "one launch at a time: avg_launch_ms is the mean HIP-event duration of the kernel",
+                           ("one launch at a time: avg_launch_ms is the mean HIP-event duration of the launch's render step — "
+                            "render_blocks followed by tail_stream, which finishes the paths the workgroups hand over (RT_OPT_TAIL_SPILL); "
+                            "tail_avg_launch_ms is tail_stream's share of it"
+                            if blk.get("tail_ms") else
+                            "one launch at a time: avg_launch_ms is the mean HIP-event duration of the kernel"),
+            "tail_avg_launch_ms": round(blk["tail_ms"] / launches, 5) if blk.get("tail_ms") else None,
             "resolve_avg_launch_ms": round(blk["resolve_ms"] / launches, 5),
             "launches": launches,
             "alg_bytes_per_launch": round(b_alg / launches, 1),

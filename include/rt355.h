@@ -75,7 +75,8 @@ typedef struct rt_stats {
   uint32_t last_stage;        /* render_tiles (variant 0/1): what that launch staged into LDS: 0 nothing, 1 sphere
                                  records, 2 the whole scene image, 3 sphere records + the sphere grid (secondary rays
                                  walk the grid); render_blocks (variant 3): 10 * waves per workgroup + waves per SIMD
-                                 its registers are budgeted for (27 multi-frame launches, 26 with two-word direction-mask sets, 25 single frames); 40 for variant 4 */
+                                 its registers are budgeted for (27 multi-frame launches, 26 with two-word direction-mask sets, 25 single
+                                 frames), + 100 when tail_stream followed it (RT_OPT_TAIL_SPILL); 40 for variant 4 */
   uint32_t grid_cells, grid_items; /* the current scene's sphere grid (0 = none: small scene, or not buildable) */
   uint32_t dirmask_cells, dirmask_bins; /* the current scene's direction-mask table (RT_OPT_DIRMASK): cells and direction
                                            bins per cell; 0 = none                                                    */
@@ -281,6 +282,9 @@ RT355_API int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segmen
 /* HIP-event times of the history-resolve pass that follows the render kernel of a multi-frame launch
  * (rt_render_frames), most recent n launches, oldest first; ~0 for single-frame launches. */
 RT355_API int rt_get_resolve_history(rt_context *ctx, uint32_t n, float *resolve_ms);
+/* HIP-event times of tail_stream, the second render kernel of a launch with a tail spill (RT_OPT_TAIL_SPILL), most recent n
+ * launches, oldest first; 0 for launches without one.  It is part of the kernel time rt_get_frame_history reports. */
+RT355_API int rt_get_tail_history(rt_context *ctx, uint32_t n, float *tail_ms);
 /* HIP-event time from the start of the oldest to the end of the newest render kernel of the most recent n launches:
  * with several launches in flight (RT_OPT_INFLIGHT, RT_OPT_BATCH_INFLIGHT) the kernel times of rt_get_frame_history
  * overlap and their sum counts the device more than once; this span does not. */
@@ -327,10 +331,13 @@ enum {
   RT_OPT_DIRMASK_MIN = 10,  /* fewest spheres that get the table (default 26)                                            */
   RT_OPT_DIRMASK_CELLS = 11,/* cells the table's grid aims at (default 4096; cubic cells, at most 64 per axis)           */
   RT_OPT_DIRMASK_K = 12,    /* direction bins per cube-map face edge, 1..16 (default 12: 864 bins)                       */
-  RT_OPT_TAIL_SPILL = 13,   /* multi-frame launches of the re-packing shape on a scene with a direction-mask table: a workgroup
-                             * whose paths that hit number at most this many (0..128; 0 = off) hands them to a path queue in
-                             * device memory and ends; a second kernel takes them up into full waves for their remaining bounces
-                             * (bit-identical; the queue takes 80 B per path, at most workgroups x threshold of them)          */
+  RT_OPT_TAIL_SPILL = 13,   /* sample-only launches of the re-packing shape (every rt_render_frames launch, and single frames in
+                             * flight) on a scene with a direction-mask table: a workgroup whose paths that hit number at most
+                             * this many (0..128, default 32; 0 = off) hands them — path state + pending hit, 80 B — to a path
+                             * queue in device memory and ends; a second kernel, tail_stream, takes them up into full waves for
+                             * their remaining bounces instead of letting each workgroup bounce its last few paths on in a
+                             * mostly empty wave (bit-identical; +5 % at 1080p, +9 % at 3840x2160).  The queue holds at most
+                             * workgroups x threshold records (0.33 GB for 8 frames of 1080p); above 4 GiB the threshold shrinks */
   RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 1): as RT_OPT_INFLIGHT,
                               each launch staging its samples in a buffer of its own; the history is updated in frame
                               order on the context's stream.  2 hides the resolve pass and the gap between launches

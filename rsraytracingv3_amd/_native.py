@@ -18,7 +18,7 @@ RT_OUT_RGBA8, RT_OUT_RGBF32, RT_OUT_SEGMENTS, RT_OUT_HITS = 1, 2, 4, 8
 RT_OPT_VARIANT, RT_OPT_REFILL_MIN, RT_OPT_BLOCKS_PER_CU, RT_OPT_TILE_CHUNK, RT_OPT_FLAGS, RT_OPT_CULL = 0, 1, 2, 3, 4, 5
 RT_OPT_INFLIGHT, RT_OPT_GRID_MIN, RT_OPT_BATCH_INFLIGHT = 6, 7, 8
 RT_OPT_DIRMASK, RT_OPT_DIRMASK_MIN, RT_OPT_DIRMASK_CELLS, RT_OPT_DIRMASK_K, RT_OPT_TAIL_SPILL = 9, 10, 11, 12, 13
-RT_TAIL_SPILL_DEFAULT = 0  # kDefaultTailSpill (csrc/rt_device.h)
+RT_TAIL_SPILL_DEFAULT = 32  # kDefaultTailSpill (csrc/rt_device.h)
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_NOT_READY",
                 -4: "RT_ERR_DEVICE", -5: "RT_ERR_OUT_OF_MEMORY"}
@@ -128,6 +128,7 @@ SIGNATURES = {
     "rt_get_counter_words": (_i, [_vp, _vp]),
     "rt_get_frame_history": (_i, [_vp, _u32, _vp, _vp, _vp]),
     "rt_get_resolve_history": (_i, [_vp, _u32, _vp]),
+    "rt_get_tail_history": (_i, [_vp, _u32, _vp]),
     "rt_get_launch_span": (_i, [_vp, _u32, _vp]),
     "rt_set_stream": (_i, [_vp, _vp]),
     "rt_bind_outputs": (_i, [_vp, _vp, _vp, _vp]),

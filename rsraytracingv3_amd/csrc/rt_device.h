@@ -79,6 +79,8 @@ constexpr int kDefaultDirmaskK = 12;           // RT_OPT_DIRMASK_K
 constexpr int kDefaultGridMinSpheres = 129;    // RT_OPT_GRID_MIN
 constexpr int kDefaultInflight = 4;            // RT_OPT_INFLIGHT
 constexpr int kDefaultBatchInflight = 1;       // RT_OPT_BATCH_INFLIGHT
+constexpr int kDefaultTailSpill = 32;          // RT_OPT_TAIL_SPILL (A/B on one device, thresholds 0 / 24 / 32 / 40: headline 50.3 / 52.9 / 52.9 /
+                                               // 52.8 Grays/s, 80 slots 44.7 / 47.7 / 48.0 / 47.9, 3840x2160 54.2 / 58.5 / 58.9 / 58.9)
 
 struct FrameParams {
   uint32_t width, height;      // full frame (Config.width/height, scene.rs:267-268)
@@ -180,6 +182,7 @@ struct LaunchConfig {
                           // takes off the queue per counter increment
   int stream_blocks;      // variant 4: grid size of the bounce pass (resident workgroups)
   int tail_blocks;        // variant 3 with a tail spill (FrameParams::spill_max): grid size of tail_stream (resident workgroups)
+  hipEvent_t tail_start;  // ... and an event to record between render_blocks and tail_stream (null: none)
   int flags;              // reserved for experiment switches
 };
 int persistent_blocks_per_cu(size_t lds_bytes);
@@ -193,7 +196,6 @@ int stream_blocks_per_cu(size_t lds_bytes);
 // Tail spill (FrameParams::spill_max): the threshold this launch would run with when `wanted` is asked for (0: the launch
 // shape, the scene or the queue budget rule it out) and the records per queue shard it needs (five float4 planes of
 // kQueueShards shards); resident workgroups per CU of tail_stream.
-constexpr int kDefaultTailSpill = 0;           // RT_OPT_TAIL_SPILL
 constexpr size_t kTailQueueBudget = 4ull << 30;  // bytes of queue a launch may ask for; the threshold shrinks to fit
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap);
 int tail_blocks_per_cu(size_t lds_bytes);

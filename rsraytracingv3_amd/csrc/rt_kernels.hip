@@ -2244,14 +2244,26 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
       }
       if (spill) {  // the spilled paths' remaining bounces, in full waves
         if (stage_used) *stage_used += 100;
+        if (lc.tail_start != nullptr) (void)hipEventRecord(lc.tail_start, stream);
         const uint32_t blocks2 = static_cast<uint32_t>(lc.tail_blocks < 1 ? 1 : lc.tail_blocks);
         const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
         hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES>), dim3(blocks2), dim3(RT_TAIL_NW * 64),
                            lds_image + RT_TAIL_NW * kScanScratchBytes, stream, sc, fp, static_cast<uint32_t>(lc.refill_min), chunk);
       }
     } else if (lean) {
+      const bool spill = fp.spill_max != 0u && fp.queue != nullptr;
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
-      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      if (spill) {
+        if (stage_used) *stage_used += 100;
+        hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+        if (lc.tail_start != nullptr) (void)hipEventRecord(lc.tail_start, stream);
+        const uint32_t blocks2 = static_cast<uint32_t>(lc.tail_blocks < 1 ? 1 : lc.tail_blocks);
+        const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
+        hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES>), dim3(blocks2), dim3(RT_TAIL_NW * 64),
+                           lds_image + RT_TAIL_NW * kScanScratchBytes, stream, sc, fp, static_cast<uint32_t>(lc.refill_min), chunk);
+      } else {
+        hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      }
     } else {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
       hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, false>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
@@ -2310,8 +2322,10 @@ int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n,
 
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap) {
   if (shard_cap) *shard_cap = 0;
-  // multi-frame sample-only launches of the re-packing shape whose secondary rays use the balanced scan (tail_stream has its scratch)
-  if (wanted == 0u || !RT_PACK_HITS || fp.batch < 2u || !sample_only(fp) || !sc.dm.enabled || pick_variant(sc, fp, lc) != 3) return 0u;
+  // sample-only launches of the re-packing shape whose secondary rays use the balanced scan (tail_stream has its scratch)
+  // (RT_OPT_FLAGS bit 2: not in single-frame launches — A/B)
+  if (wanted == 0u || !RT_PACK_HITS || !sample_only(fp) || !sc.dm.enabled || pick_variant(sc, fp, lc) != 3) return 0u;
+  if (fp.batch < 2u && (lc.flags & 4)) return 0u;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile, tiles_y = (fp.local_rows + kTile - 1) / kTile;
   const uint64_t blocks = static_cast<uint64_t>((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW) * tiles_y * fp.batch;  // render_blocks' grid
   const uint64_t per_shard = (blocks + kQueueShards - 1) / kQueueShards;  // workgroups that append to one shard, each once

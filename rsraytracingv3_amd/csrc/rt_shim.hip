@@ -39,6 +39,8 @@ struct rt_context {
   static constexpr uint32_t kTileWords = kQueueHeadWords;  // u32 words per ring slot: variant 2's 8 work counters / variant 4's
                                                           // 2 x kQueueShards queue heads, 128 B apart
   std::vector<hipEvent_t> ev_start, ev_stop, ev_resolved;  // render kernel = start..stop, resolve pass = stop..resolved
+  std::vector<hipEvent_t> ev_tail;                         // recorded between render_blocks and tail_stream (tail spill)
+  std::vector<unsigned char> tail_ran;                     // the launch in that ring slot had a tail_stream
   bool timing_valid = false;
 
   // skybox
@@ -408,9 +410,11 @@ int rt_create(int device_id, rt_context **out_ctx) {
   ctx->ev_start.assign(rt_context::kRing, nullptr);
   ctx->ev_stop.assign(rt_context::kRing, nullptr);
   ctx->ev_resolved.assign(rt_context::kRing, nullptr);
+  ctx->ev_tail.assign(rt_context::kRing, nullptr);
+  ctx->tail_ran.assign(rt_context::kRing, 0);
   for (uint32_t i = 0; i < rt_context::kRing; ++i)
     if (hipEventCreate(&ctx->ev_start[i]) != hipSuccess || hipEventCreate(&ctx->ev_stop[i]) != hipSuccess ||
-        hipEventCreate(&ctx->ev_resolved[i]) != hipSuccess)
+        hipEventCreate(&ctx->ev_resolved[i]) != hipSuccess || hipEventCreate(&ctx->ev_tail[i]) != hipSuccess)
       return bail(RT_ERR_DEVICE);
   for (int i = 0; i < 2; ++i)
     if (hipEventCreateWithFlags(&ctx->rnd_last_use[i], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
@@ -473,6 +477,8 @@ int rt_destroy(rt_context *ctx) {
   for (hipEvent_t e : ctx->ev_stop)
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_resolved)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_tail)
     if (e) (void)hipEventDestroy(e);
   if (ctx->stream && ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
@@ -1421,9 +1427,11 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
         }
         const int per_cu_tail = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->tail_occupancy_blocks > 0 ? ctx->tail_occupancy_blocks : 4);
         lc.tail_blocks = per_cu_tail * ctx->cu_count;
+        lc.tail_start = ctx->ev_tail[slot];
       }
     }
   }
+  ctx->tail_ran[slot] = fp.spill_max != 0u;
   RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], render_stream));
   int per_cu = ctx->blocks_per_cu;
   if (per_cu <= 0 && ctx->variant == 2) {  // only the resident-wave shape sizes its grid by occupancy
@@ -1686,6 +1694,21 @@ int rt_get_resolve_history(rt_context *ctx, uint32_t n, float *resolve_ms) {
   for (uint32_t k = 0; k < n; ++k) {  // oldest first
     const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - n + k) % rt_context::kRing);
     RT_HIP(ctx, hipEventElapsedTime(&resolve_ms[k], ctx->ev_stop[slot], ctx->ev_resolved[slot]));
+  }
+  return RT_OK;
+}
+
+int rt_get_tail_history(rt_context *ctx, uint32_t n, float *tail_ms) {
+  if (!ctx || !tail_ms) return RT_ERR_INVALID_ARGUMENT;
+  if (n > rt_context::kRing / 2 || n > ctx->stats.frames)
+    return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_get_tail_history: %u launches asked, %llu made, ring keeps %u", n,
+                static_cast<unsigned long long>(ctx->stats.frames), rt_context::kRing / 2);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (uint32_t k = 0; k < n; ++k) {  // oldest first
+    const uint32_t slot = static_cast<uint32_t>((ctx->stats.frames - n + k) % rt_context::kRing);
+    tail_ms[k] = 0.0f;
+    if (ctx->tail_ran[slot]) RT_HIP(ctx, hipEventElapsedTime(&tail_ms[k], ctx->ev_tail[slot], ctx->ev_stop[slot]));
   }
   return RT_OK;
 }

@@ -427,14 +427,20 @@ def test_tail_spill_hands_the_last_paths_to_full_waves(device, case):
             device.set_option(N.RT_OPT_TAIL_SPILL, t)
             device.set_option(N.RT_OPT_REFILL_MIN, refill_min)
             device.set_option(N.RT_OPT_TILE_CHUNK, chunk)
-            (_, bat), st = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 3, partition, slots)
+            (seq_t, bat), st = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 3, partition, slots)
             assert st.last_variant == 3 and st.last_stage >= 100, "the launch did not take the spilling shape"
             assert (st.last_segments, st.last_rough_hits) == (st0.last_segments, st0.last_rough_hits)
             assert np.array_equal(seq[0], bat[0]), "threshold %d: texels differ" % t
             assert np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32)), "threshold %d: floats differ" % t
-        # single-frame launches and scenes without a table never spill
+            # the sequential frames of that run were single-frame launches in flight, which spill as well
+            assert np.array_equal(seq[0], seq_t[0]) and np.array_equal(seq[1].view(np.uint32), seq_t[1].view(np.uint32))
+            tail_ms = np.zeros(1, np.float32)
+            device.call("rt_get_tail_history", 1, tail_ms.ctypes.data_as(C.c_void_p))
+            assert 0.0 < tail_ms[0] < st.last_kernel_ms, "tail_stream's time is part of the launch's kernel time"
+        # a launch with per-frame diagnostic outputs is not sample-only: no spill
         outs, st1 = run_gpu(device, scene, (96, 64), sky, rnd, (0.0, 0.0), variant=3, max_objects=slots)
         assert st1.last_stage < 100
+        assert_frame_equal(outs[0], run_oracle(scene, (96, 64), sky, rnd, (0.0, 0.0), max_objects=slots))
     finally:
         device.set_option(N.RT_OPT_TAIL_SPILL, N.RT_TAIL_SPILL_DEFAULT)
         device.set_option(N.RT_OPT_REFILL_MIN, 1)

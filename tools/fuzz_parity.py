@@ -62,7 +62,7 @@ def run(cases=100, first=0):
     dev = Device(0)
     multi = MultiDevice([0, 0, 0], 8)  # every seventh case also goes through three contexts of one process (rt_multi_*)
     sky = synth.procedural_skybox(128, 64)
-    bad = grids = tables = multis = 0
+    bad = grids = tables = multis = spills = 0
     for seed in range(first, first + cases):
         scene, size, jitter, slots, variant, tex_seed = random_case(seed)
         rnd = synth.random_texture(tex_seed)
@@ -98,9 +98,17 @@ def run(cases=100, first=0):
             jit = rs.uniform(-0.495, 0.495, (nf, 2)).astype(np.float32)
             dev.set_accum_mode(accum)
             dev.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
+            if variant == 3:  # sample-only launches of the re-packing shape: the tail spill at several thresholds
+                dev.set_option(N.RT_OPT_CULL, 1)  # (the self-check frames of RT_OPT_CULL = 2 are not sample-only)
+                dev.set_option(N.RT_OPT_TAIL_SPILL, (4, 32, 128)[(seed // 2) % 3])
+                dev.set_option(N.RT_OPT_REFILL_MIN, (1, 16, 64)[(seed // 6) % 3])
             target = RenderTarget.new(dev, size)
             conn.draw_frames(jit, pc0)
             dev.sync()
+            spills += dev.stats().last_stage >= 100
+            dev.set_option(N.RT_OPT_CULL, 2)
+            dev.set_option(N.RT_OPT_TAIL_SPILL, N.RT_TAIL_SPILL_DEFAULT)
+            dev.set_option(N.RT_OPT_REFILL_MIN, 1)
             hist8 = np.zeros((h, w, 4), np.uint8) if accum == 0 else None
             histf = np.zeros((h, w, 3), np.float32) if accum == 1 else None
             for k in range(nf):
@@ -143,8 +151,9 @@ def run(cases=100, first=0):
     dev.set_option(N.RT_OPT_GRID_MIN, 129)
     dev.close()
     multi.close()
-    print("fuzz: %d cases from seed %d (%d of them walked a sphere grid, %d used a direction-mask table, %d also went through a "
-          "three-context rt_multi), %d mismatching" % (cases, first, grids, tables, multis, bad), flush=True)
+    print("fuzz: %d cases from seed %d (%d of them walked a sphere grid, %d used a direction-mask table, %d multi-frame launches "
+          "spilled their tail, %d also went through a three-context rt_multi), %d mismatching"
+          % (cases, first, grids, tables, spills, multis, bad), flush=True)
     return bad
 
 

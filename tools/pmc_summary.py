@@ -31,7 +31,9 @@ ap.add_argument("--objects", type=int, default=65)
 ap.add_argument("--bounces", type=int, default=8)
 ap.add_argument("--sky-width", type=int, default=2048)
 args = ap.parse_args()
-KERNELS = {"render_kernel": "render_", "resolve_kernel": "resolve_batch_kernel"}
+# a launch's render step may be two kernels: render_blocks, then tail_stream (RT_OPT_TAIL_SPILL); their per-launch averages are
+# summed into "render_kernel" below, and kept apart under "render_parts"
+KERNELS = {"render_kernel": "render_", "tail_kernel": "tail_stream", "resolve_kernel": "resolve_batch_kernel"}
 merged = {k: {} for k in KERNELS}
 names = {k: set() for k in KERNELS}
 counts = {k: {} for k in KERNELS}
@@ -42,7 +44,7 @@ for d in args.dirs:
             for key, pat in KERNELS.items():
                 if pat in r["Kernel_Name"]:
                     acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    m = re.search(r"(render_\w+(?:<[\d, ]+>)?|resolve_batch_kernel)", r["Kernel_Name"])
+                    m = re.search(r"((?:render_|tail_)\w+(?:<[\w, ]+>)?|resolve_batch_kernel)", r["Kernel_Name"])
                     names[key].add(m.group(1) if m else r["Kernel_Name"])
         for key in KERNELS:
             # launches of the warm-up may carry fewer frames; keep the modal half (the timed launches) by median
@@ -63,7 +65,15 @@ if args.json:
                 "(profiles/r01_fetch_size_calibration.md); resolve kernel: coalesced streams, FETCH_SIZE doubled "
                 "(MI355X_MICROARCH.md, HBM).  valu_issue_util = SQ_INSTS_VALU * 2 / (1024 SIMDs * GRBM_GUI_ACTIVE / 8).",
     }
-    for key in KERNELS:
+    if merged["tail_kernel"]:  # the launch's render step = both kernels
+        parts = {}
+        for key in ("render_kernel", "tail_kernel"):
+            parts[", ".join(sorted(names[key]))] = {c: round(v, 2) for c, v in sorted(merged[key].items())}
+        out["render_parts"] = parts
+        for c, v in merged["tail_kernel"].items():
+            merged["render_kernel"][c] = merged["render_kernel"].get(c, 0.0) + v
+        names["render_kernel"] = {" + ".join(sorted(names["render_kernel"]) + sorted(names["tail_kernel"]))}
+    for key in ("render_kernel", "resolve_kernel"):
         m = merged[key]
         fetch = m.get("FETCH_SIZE", 0.0) * 1024.0 * (2.0 if key == "resolve_kernel" else 1.0)
         write = m.get("WRITE_SIZE", 0.0) * 1024.0
