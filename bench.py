@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--dirmask-cells", type=int, default=0, help="RT_OPT_DIRMASK_CELLS (0 = library default)")
     ap.add_argument("--tail-spill", type=int, default=-1,
                     help="RT_OPT_TAIL_SPILL: workgroups with at most this many paths left hand them to the tail kernel (0 = off, -1 = library default)")
+    ap.add_argument("--tail-spill-single", type=int, default=-1, help="RT_OPT_TAIL_SPILL_SINGLE: the same for single-frame launches (-1 = library default 0)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive 1-spp frames per kernel launch (rt_render_frames, 1..64); 0 = 8 per GPU of the job, "
                          "so that a launch carries eight frames' worth of tiles whatever the partition")
@@ -164,6 +165,8 @@ def main():
         dev.set_option(N.RT_OPT_DIRMASK_CELLS, args.dirmask_cells)
     if args.tail_spill >= 0:
         dev.set_option(N.RT_OPT_TAIL_SPILL, args.tail_spill)
+    if args.tail_spill_single >= 0:
+        dev.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, args.tail_spill_single)
     target = RenderTarget.new(dev, (W, H))
     rt = RandomTexture(dev)
     rt.write(rnd)
@@ -409,7 +412,7 @@ def main():
         prof_key = dict(prof.get("workload_key", {}))
         prof_key.pop("frames_per_launch", None)  # the profile's launches carried 8 frames; traffic is taken per frame
         tuned = (args.variant != -1 or args.dirmask >= 0 or args.dirmask_k or args.dirmask_cells or args.grid_min or args.flags or
-                 args.batch_inflight != 1 or args.blocks_per_cu or args.refill_min != 1 or args.tile_chunk != 2 or args.tail_spill >= 0)
+                 args.batch_inflight != 1 or args.blocks_per_cu or args.refill_min != 1 or args.tile_chunk != 2 or args.tail_spill >= 0 or args.tail_spill_single >= 0)
         if prof_key != workload_key or B <= 1 or tuned:  # the profile was collected with the library's defaults
             continue
         if prof.get("kernel_source_sha256") != source_now:

@@ -331,8 +331,11 @@ enum {
   RT_OPT_DIRMASK_MIN = 10,  /* fewest spheres that get the table (default 26)                                            */
   RT_OPT_DIRMASK_CELLS = 11,/* cells the table's grid aims at (default 4096; cubic cells, at most 64 per axis)           */
   RT_OPT_DIRMASK_K = 12,    /* direction bins per cube-map face edge, 1..16 (default 12: 864 bins)                       */
-  RT_OPT_TAIL_SPILL = 13,   /* sample-only launches of the re-packing shape (every rt_render_frames launch, and single frames in
-                             * flight) on a scene with a direction-mask table: a workgroup whose paths that hit number at most
+  RT_OPT_TAIL_SPILL_SINGLE = 14, /* the same threshold for single-frame launches in flight (rt_render with RT_OPT_INFLIGHT >= 2 and no
+                             * diagnostic outputs); default 0 = off: tail_stream costs a single frame ~35 us whatever it holds,
+                             * which only pays in long uninterrupted runs of frames (+1..2 %)                              */
+  RT_OPT_TAIL_SPILL = 13,   /* multi-frame launches (rt_render_frames) of the re-packing shape on a scene with a
+                             * direction-mask table: a workgroup whose paths that hit number at most
                              * this many (0..128, default 32; 0 = off) hands them — path state + pending hit, 80 B — to a path
                              * queue in device memory and ends; a second kernel, tail_stream, takes them up into full waves for
                              * their remaining bounces instead of letting each workgroup bounce its last few paths on in a

@@ -19,6 +19,7 @@ RT_OPT_VARIANT, RT_OPT_REFILL_MIN, RT_OPT_BLOCKS_PER_CU, RT_OPT_TILE_CHUNK, RT_O
 RT_OPT_INFLIGHT, RT_OPT_GRID_MIN, RT_OPT_BATCH_INFLIGHT = 6, 7, 8
 RT_OPT_DIRMASK, RT_OPT_DIRMASK_MIN, RT_OPT_DIRMASK_CELLS, RT_OPT_DIRMASK_K, RT_OPT_TAIL_SPILL = 9, 10, 11, 12, 13
 RT_TAIL_SPILL_DEFAULT = 32  # kDefaultTailSpill (csrc/rt_device.h)
+RT_OPT_TAIL_SPILL_SINGLE = 14  # default 0
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_NOT_READY",
                 -4: "RT_ERR_DEVICE", -5: "RT_ERR_OUT_OF_MEMORY"}

@@ -79,6 +79,9 @@ constexpr int kDefaultDirmaskK = 12;           // RT_OPT_DIRMASK_K
 constexpr int kDefaultGridMinSpheres = 129;    // RT_OPT_GRID_MIN
 constexpr int kDefaultInflight = 4;            // RT_OPT_INFLIGHT
 constexpr int kDefaultBatchInflight = 1;       // RT_OPT_BATCH_INFLIGHT
+constexpr int kDefaultTailSpillSingle = 0;     // RT_OPT_TAIL_SPILL_SINGLE: single frames in flight do not spill (A/B on one device, one frame per
+                                               // launch, threshold 0 / 32: 47.0 / 47.4 - 48.0 Grays/s in runs of 200 frames, 45.1 / 43.3 in runs of 20:
+                                               // tail_stream's fixed ~35 us per launch pay only in long uninterrupted runs)
 constexpr int kDefaultTailSpill = 32;          // RT_OPT_TAIL_SPILL (A/B on one device, thresholds 0 / 24 / 32 / 40: headline 50.3 / 52.9 / 52.9 /
                                                // 52.8 Grays/s, 80 slots 44.7 / 47.7 / 48.0 / 47.9, 3840x2160 54.2 / 58.5 / 58.9 / 58.9)
 

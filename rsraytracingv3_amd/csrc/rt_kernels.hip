@@ -2323,9 +2323,7 @@ int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n,
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap) {
   if (shard_cap) *shard_cap = 0;
   // sample-only launches of the re-packing shape whose secondary rays use the balanced scan (tail_stream has its scratch)
-  // (RT_OPT_FLAGS bit 2: not in single-frame launches — A/B)
   if (wanted == 0u || !RT_PACK_HITS || !sample_only(fp) || !sc.dm.enabled || pick_variant(sc, fp, lc) != 3) return 0u;
-  if (fp.batch < 2u && (lc.flags & 4)) return 0u;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile, tiles_y = (fp.local_rows + kTile - 1) / kTile;
   const uint64_t blocks = static_cast<uint64_t>((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW) * tiles_y * fp.batch;  // render_blocks' grid
   const uint64_t per_shard = (blocks + kQueueShards - 1) / kQueueShards;  // workgroups that append to one shard, each once

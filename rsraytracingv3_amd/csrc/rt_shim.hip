@@ -88,6 +88,7 @@ struct rt_context {
   int cu_count = 0;
   int tile_chunk = 2;       // RT_OPT_TILE_CHUNK
   int tail_spill = kDefaultTailSpill;  // RT_OPT_TAIL_SPILL: a workgroup with at most this many paths left hands them to tail_stream
+  int tail_spill_single = kDefaultTailSpillSingle;  // RT_OPT_TAIL_SPILL_SINGLE: the same for single-frame launches in flight
   int tail_occupancy_blocks = 0;       // resident tail_stream workgroups per CU for tail_occupancy_records of scene image
   uint32_t tail_occupancy_records = 0;
   int flags = 0;            // RT_OPT_FLAGS
@@ -1092,6 +1093,10 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       if (value < 0 || value > 128) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TAIL_SPILL takes 0..128");
       ctx->tail_spill = value;
       return RT_OK;
+    case RT_OPT_TAIL_SPILL_SINGLE:
+      if (value < 0 || value > 128) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TAIL_SPILL_SINGLE takes 0..128");
+      ctx->tail_spill_single = value;
+      return RT_OK;
     case RT_OPT_BATCH_INFLIGHT:
       if (value < 1 || value > rt_context::kMaxInflight)
         return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BATCH_INFLIGHT takes 1..%d", rt_context::kMaxInflight);
@@ -1396,9 +1401,10 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     lc.stream_blocks = per_cu_stream * ctx->cu_count;
   }
   fp.spill_max = 0;
-  if (ctx->tail_spill > 0 && fp.queue == nullptr) {  // tail spill of the re-packing shape: needs the queue and tail_stream's grid
+  const int spill_wanted = batch > 1u ? ctx->tail_spill : ctx->tail_spill_single;
+  if (spill_wanted > 0 && fp.queue == nullptr) {  // tail spill of the re-packing shape: needs the queue and tail_stream's grid
     uint32_t shard_cap = 0;
-    const uint32_t t = tail_spill_plan(ctx->scene, fp, lc, static_cast<uint32_t>(ctx->tail_spill), &shard_cap);
+    const uint32_t t = tail_spill_plan(ctx->scene, fp, lc, static_cast<uint32_t>(spill_wanted), &shard_cap);
     if (t != 0u) {
       const int qi = pipelined ? lane : static_cast<int>(rt_context::kMaxInflight);
       const size_t plane = static_cast<size_t>(shard_cap) * kQueueShards;

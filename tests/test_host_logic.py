@@ -147,10 +147,21 @@ def test_trace_union_counts_shared_device_time_once(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "trace_union.py"), str(d)], capture_output=True, text=True,
                          check=True).stdout
-    assert "last 3 dispatches" in out
-    assert "mean kernel duration          0.0017 ms" in out          # (2000 + 2000 + 1000) / 3 ns
+    assert "last 3 launches (1 kernel(s) each)" in out
+    assert "mean kernel time per launch   0.0017 ms" in out          # (2000 + 2000 + 1000) / 3 ns
     assert "device time per launch        0.0013 ms" in out          # union 3000 + 1000 = 4000 / 3 ns
     assert "kernels running at once       1.25" in out
+    # a launch whose render step is two kernels (render_blocks, then tail_stream): both count towards the launch
+    rows = rows[:1]
+    for k, (s, e, name) in enumerate([(1000, 3000, "render_blocks<2, 7, true, true>"), (3100, 3600, "tail_stream<2, 5>"),
+                                      (5000, 7000, "render_blocks<2, 7, true, true>"), (7100, 7600, "tail_stream<2, 5>")]):
+        rows.append('"KERNEL_DISPATCH","Agent 2",1,0,1,%d,1,"%s",%d,%d,%d' % (k, name, k, s, e))
+    (d / "x_kernel_trace.csv").write_text("\n".join(rows) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "trace_union.py"), str(d)], capture_output=True, text=True,
+                         check=True).stdout
+    assert "last 2 launches (2 kernel(s) each)" in out
+    assert "mean kernel time per launch   0.0025 ms" in out          # (2000 + 500) ns per launch
+    assert "kernels running at once       1.00" in out
 
 
 def test_committed_bench_line_keeps_the_contract():

@@ -420,11 +420,13 @@ def test_tail_spill_hands_the_last_paths_to_full_waves(device, case):
     jit = [(0.1, -0.2), (-0.33, 0.27), (0.45, 0.05), (-0.49, -0.49), (0.0, 0.31), (0.2, 0.2)]
     try:
         device.set_option(N.RT_OPT_TAIL_SPILL, 0)
+        device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, 0)
         (seq, bat0), st0 = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 3, partition, slots)
         assert st0.last_variant == 3 and st0.last_stage < 100 and st0.dirmask_cells > 0
         assert np.array_equal(seq[0], bat0[0]) and np.array_equal(seq[1].view(np.uint32), bat0[1].view(np.uint32))
         for t, refill_min, chunk in ((4, 1, 1), (24, 16, 2), (64, 9, 3), (128, 64, 1), (32, 1, 2)):
             device.set_option(N.RT_OPT_TAIL_SPILL, t)
+            device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, t)
             device.set_option(N.RT_OPT_REFILL_MIN, refill_min)
             device.set_option(N.RT_OPT_TILE_CHUNK, chunk)
             (seq_t, bat), st = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 3, partition, slots)
@@ -443,6 +445,7 @@ def test_tail_spill_hands_the_last_paths_to_full_waves(device, case):
         assert_frame_equal(outs[0], run_oracle(scene, (96, 64), sky, rnd, (0.0, 0.0), max_objects=slots))
     finally:
         device.set_option(N.RT_OPT_TAIL_SPILL, N.RT_TAIL_SPILL_DEFAULT)
+        device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, 0)
         device.set_option(N.RT_OPT_REFILL_MIN, 1)
         device.set_option(N.RT_OPT_TILE_CHUNK, 2)
         device.set_partition(0, 1, 8)

@@ -10,7 +10,7 @@ for rep in 1 2; do
   for t in $ts; do
     python bench.py --tail-spill $t --no-cpu-baseline --min-seconds 0.6 --clock-warmup 1.0 2>/dev/null | line "T=$t rep $rep" | tee -a "$out"
   done
-  python bench.py --tail-spill 32 --flags 4 --no-cpu-baseline --min-seconds 0.6 --clock-warmup 1.0 2>/dev/null | line "T=32 batch only rep $rep" | tee -a "$out"
+  python bench.py --tail-spill 32 --tail-spill-single 32 --no-cpu-baseline --min-seconds 0.6 --clock-warmup 1.0 2>/dev/null | line "T=32, single frames too, rep $rep" | tee -a "$out"
 done
 for t in $ts; do
   python bench.py --tail-spill $t --width 3840 --height 2160 --no-cpu-baseline --no-extra-legs --min-seconds 0.6 --clock-warmup 1.0 2>/dev/null | line "4K T=$t" | tee -a "$out"

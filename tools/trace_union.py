@@ -22,22 +22,27 @@ import sys
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("directory")
-    ap.add_argument("--kernel", default="render_blocks")
+    ap.add_argument("--kernel", default="render_blocks,tail_stream",
+                    help="comma-separated name fragments: a launch's render step is render_blocks followed by tail_stream")
     ap.add_argument("--last", type=int, default=200)
     args = ap.parse_args()
     paths = glob.glob(os.path.join(args.directory, "**", "*kernel_trace.csv"), recursive=True)
     if not paths:
         sys.exit("no *kernel_trace.csv under %s" % args.directory)
     spans = []
+    kernels = [k for k in args.kernel.split(",") if k]
+    launches = 0  # dispatches of the first kernel named = launches
     for path in paths:
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                if args.kernel in row["Kernel_Name"]:
+                if any(k in row["Kernel_Name"] for k in kernels):
                     spans.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+                    launches += kernels[0] in row["Kernel_Name"]
     if not spans:
         sys.exit("no dispatch of a kernel named *%s*" % args.kernel)
     spans.sort()
-    spans = spans[-args.last:]
+    per_launch = max(1, round(len(spans) / max(launches, 1)))  # kernels per launch (2 with a tail_stream)
+    spans = spans[-args.last * per_launch:]
     total = sum(e - s for s, e in spans)
     union, cur_s, cur_e = 0, spans[0][0], spans[0][1]
     for s, e in spans[1:]:
@@ -47,10 +52,10 @@ def main():
         else:
             cur_e = max(cur_e, e)
     union += cur_e - cur_s
-    n = len(spans)
-    print("%s: last %d dispatches" % (args.kernel, n))
-    print("  mean kernel duration          %.4f ms" % (total / n * 1e-6))
-    print("  device time per launch        %.4f ms   (union of the intervals / dispatches)" % (union / n * 1e-6))
+    n = len(spans) // per_launch
+    print("%s: last %d launches (%d kernel(s) each)" % (" + ".join(kernels), n, per_launch))
+    print("  mean kernel time per launch   %.4f ms   (sum of the durations / launches)" % (total / n * 1e-6))
+    print("  device time per launch        %.4f ms   (union of the intervals / launches)" % (union / n * 1e-6))
     print("  kernels running at once       %.2f" % (total / union))
     print("  first start .. last end       %.4f ms per launch" % ((spans[-1][1] - spans[0][0]) / n * 1e-6))
 
