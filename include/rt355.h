@@ -311,7 +311,8 @@ enum {
   RT_OPT_BLOCKS_PER_CU = 2,/* variants 2 and 4: resident workgroups per CU (0 = occupancy query) */
   RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump; variant 4: 64-path
                               units a wave takes off the path queue at a time */
-  RT_OPT_FLAGS = 4,        /* experiment switches (speed only)                                     */
+  RT_OPT_FLAGS = 4,        /* experiment switches (speed only): bit 1 (2) ignore the sphere grid; bit 2 (4) launches of every
+                              size spill their tail (RT_OPT_TAIL_SPILL)                             */
   RT_OPT_CULL = 5,         /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
                               scan is re-done in full and disagreements are counted in rt_stats     */
   RT_OPT_INFLIGHT = 6,     /* single-frame launches (rt_render / rt_render_frame) in flight at once, 1..8 (default 4):
@@ -334,8 +335,8 @@ enum {
   RT_OPT_TAIL_SPILL_SINGLE = 14, /* the same threshold for single-frame launches in flight (rt_render with RT_OPT_INFLIGHT >= 2 and no
                              * diagnostic outputs); default 0 = off: tail_stream costs a single frame ~35 us whatever it holds,
                              * which only pays in long uninterrupted runs of frames (+1..2 %)                              */
-  RT_OPT_TAIL_SPILL = 13,   /* multi-frame launches (rt_render_frames) of the re-packing shape on a scene with a
-                             * direction-mask table: a workgroup whose paths that hit number at most
+  RT_OPT_TAIL_SPILL = 13,   /* multi-frame launches (rt_render_frames) of the re-packing shape, of 100 000 tiles or more (three
+                             * 1080p frames) and two bounces or more, on a scene with a direction-mask table: a workgroup whose paths that hit number at most
                              * this many (0..128, default 32; 0 = off) hands them — path state + pending hit, 80 B — to a path
                              * queue in device memory and ends; a second kernel, tail_stream, takes them up into full waves for
                              * their remaining bounces instead of letting each workgroup bounce its last few paths on in a

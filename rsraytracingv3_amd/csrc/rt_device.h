@@ -200,6 +200,8 @@ int stream_blocks_per_cu(size_t lds_bytes);
 // shape, the scene or the queue budget rule it out) and the records per queue shard it needs (five float4 planes of
 // kQueueShards shards); resident workgroups per CU of tail_stream.
 constexpr size_t kTailQueueBudget = 4ull << 30;  // bytes of queue a launch may ask for; the threshold shrinks to fit
+constexpr uint64_t kTailMinTiles = 100000;       // 8x8 tiles from which a launch spills (1080p: 2 frames per launch 42.8 Grays/s without /
+                                                 // 41.0 with the spill, 4 frames 47.6 / 48.7, 8 frames 50.2 / 52.2: from three frames up)
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap);
 int tail_blocks_per_cu(size_t lds_bytes);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);

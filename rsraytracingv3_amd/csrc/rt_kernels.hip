@@ -2324,6 +2324,9 @@ uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const Lau
   if (shard_cap) *shard_cap = 0;
   // sample-only launches of the re-packing shape whose secondary rays use the balanced scan (tail_stream has its scratch)
   if (wanted == 0u || !RT_PACK_HITS || !sample_only(fp) || !sc.dm.enabled || pick_variant(sc, fp, lc) != 3) return 0u;
+  // nothing to hand over when the first shading is the last; and tail_stream costs a launch ~35 us whatever it holds, which
+  // small launches do not earn back (RT_OPT_FLAGS bit 2 lifts the size rule: tests)
+  if (fp.reflection_limit < 2u || (launch_tiles(fp) < kTailMinTiles && !(lc.flags & 4))) return 0u;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile, tiles_y = (fp.local_rows + kTile - 1) / kTile;
   const uint64_t blocks = static_cast<uint64_t>((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW) * tiles_y * fp.batch;  // render_blocks' grid
   const uint64_t per_shard = (blocks + kQueueShards - 1) / kQueueShards;  // workgroups that append to one shard, each once

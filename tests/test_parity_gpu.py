@@ -419,6 +419,7 @@ def test_tail_spill_hands_the_last_paths_to_full_waves(device, case):
     sky, rnd = cases.inputs(256, 128)
     jit = [(0.1, -0.2), (-0.33, 0.27), (0.45, 0.05), (-0.49, -0.49), (0.0, 0.31), (0.2, 0.2)]
     try:
+        device.set_option(N.RT_OPT_FLAGS, 4)  # launches of every size spill (by default only those of 100 000 tiles or more)
         device.set_option(N.RT_OPT_TAIL_SPILL, 0)
         device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, 0)
         (seq, bat0), st0 = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 3, partition, slots)
@@ -439,11 +440,17 @@ def test_tail_spill_hands_the_last_paths_to_full_waves(device, case):
             tail_ms = np.zeros(1, np.float32)
             device.call("rt_get_tail_history", 1, tail_ms.ctypes.data_as(C.c_void_p))
             assert 0.0 < tail_ms[0] < st.last_kernel_ms, "tail_stream's time is part of the launch's kernel time"
+        # by default a launch this small does not spill
+        device.set_option(N.RT_OPT_FLAGS, 0)
+        device.set_option(N.RT_OPT_TAIL_SPILL, 32)
+        (_, bat), st = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_FLOAT32, 3, partition, slots)
+        assert st.last_stage < 100 and np.array_equal(seq[0], bat[0])
         # a launch with per-frame diagnostic outputs is not sample-only: no spill
         outs, st1 = run_gpu(device, scene, (96, 64), sky, rnd, (0.0, 0.0), variant=3, max_objects=slots)
         assert st1.last_stage < 100
         assert_frame_equal(outs[0], run_oracle(scene, (96, 64), sky, rnd, (0.0, 0.0), max_objects=slots))
     finally:
+        device.set_option(N.RT_OPT_FLAGS, 0)
         device.set_option(N.RT_OPT_TAIL_SPILL, N.RT_TAIL_SPILL_DEFAULT)
         device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, 0)
         device.set_option(N.RT_OPT_REFILL_MIN, 1)

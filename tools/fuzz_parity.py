@@ -100,6 +100,7 @@ def run(cases=100, first=0):
             dev.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
             if variant == 3:  # sample-only launches of the re-packing shape: the tail spill at several thresholds
                 dev.set_option(N.RT_OPT_CULL, 1)  # (the self-check frames of RT_OPT_CULL = 2 are not sample-only)
+                dev.set_option(N.RT_OPT_FLAGS, 4)  # launches of every size spill
                 dev.set_option(N.RT_OPT_TAIL_SPILL, (4, 32, 128)[(seed // 2) % 3])
                 dev.set_option(N.RT_OPT_REFILL_MIN, (1, 16, 64)[(seed // 6) % 3])
             target = RenderTarget.new(dev, size)
@@ -107,6 +108,7 @@ def run(cases=100, first=0):
             dev.sync()
             spills += dev.stats().last_stage >= 100
             dev.set_option(N.RT_OPT_CULL, 2)
+            dev.set_option(N.RT_OPT_FLAGS, 0)
             dev.set_option(N.RT_OPT_TAIL_SPILL, N.RT_TAIL_SPILL_DEFAULT)
             dev.set_option(N.RT_OPT_REFILL_MIN, 1)
             hist8 = np.zeros((h, w, 4), np.uint8) if accum == 0 else None
