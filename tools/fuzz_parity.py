@@ -98,7 +98,9 @@ def run(cases=100, first=0):
             jit = rs.uniform(-0.495, 0.495, (nf, 2)).astype(np.float32)
             dev.set_accum_mode(accum)
             dev.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
-            if variant == 3:  # sample-only launches of the re-packing shape: the tail spill at several thresholds
+            if seed % 4 == 0:
+                dev.set_variant(3)  # every second multi-frame launch takes the re-packing shape whatever the case drew
+            if variant == 3 or seed % 4 == 0:  # sample-only launches of the re-packing shape: the tail spill at several thresholds
                 dev.set_option(N.RT_OPT_CULL, 1)  # (the self-check frames of RT_OPT_CULL = 2 are not sample-only)
                 dev.set_option(N.RT_OPT_FLAGS, 4)  # launches of every size spill
                 dev.set_option(N.RT_OPT_TAIL_SPILL, (4, 32, 128)[(seed // 2) % 3])
