@@ -164,6 +164,45 @@ def test_trace_union_counts_shared_device_time_once(tmp_path):
     assert "kernels running at once       1.00" in out
 
 
+def test_pmc_summary_adds_the_two_render_kernels_of_a_launch(tmp_path):
+    """tools/pmc_summary.py: a launch's render step is render_blocks followed by tail_stream (RT_OPT_TAIL_SPILL); the
+    per-launch figures bench.py imports are the SUM of the two kernels' per-dispatch means, the parts stay readable."""
+    import json
+    import os
+    import subprocess
+    import sys
+    d = tmp_path / "pmc1"
+    d.mkdir()
+    head = ('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id","Kernel_Name",'
+            '"Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count","Counter_Name",'
+            '"Counter_Value","Start_Timestamp","End_Timestamp"')
+    rows = [head]
+    names = {"blocks": "void rt355::(anonymous namespace)::render_blocks<2, 7, true, true>(rt355::DeviceScene, rt355::FrameParams)",
+             "tail": "void rt355::(anonymous namespace)::tail_stream<2, 5>(rt355::DeviceScene, rt355::FrameParams, unsigned int, unsigned int)",
+             "resolve": "rt355::(anonymous namespace)::resolve_batch_kernel(rt355::ResolveParams)"}
+    k = 0
+    for launch in range(8):
+        for kind, counters in (("blocks", {"FETCH_SIZE": 1000.0, "SQ_INSTS_VALU": 400.0, "GRBM_GUI_ACTIVE": 8000.0}),
+                               ("tail", {"FETCH_SIZE": 250.0, "SQ_INSTS_VALU": 100.0, "GRBM_GUI_ACTIVE": 2000.0}),
+                               ("resolve", {"FETCH_SIZE": 100.0})):
+            for c, v in counters.items():
+                k += 1
+                rows.append('%d,%d,"Agent 4",1,1,1,64,1,"%s",128,0,0,72,0,96,"%s",%f,0,1' % (k, k, names[kind], c, v))
+    (d / "x_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "traffic.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(d), "--json", str(out)], check=True,
+                   capture_output=True, text=True)
+    t = json.loads(out.read_text())
+    r = t["render_kernel"]
+    assert "render_blocks<2, 7, true, true>" in r["kernel"] and "tail_stream<2, 5>" in r["kernel"]
+    assert r["counters_per_launch"]["FETCH_SIZE"] == 1250.0 and r["fetch_bytes"] == 1250.0 * 1024
+    assert abs(r["valu_issue_util"] - 500.0 * 2.0 / (1024.0 * 10000.0 / 8.0)) < 1e-4   # over the busy cycles of both kernels
+    assert set(t["render_parts"]) == {"render_blocks<2, 7, true, true>", "tail_stream<2, 5>"}
+    assert t["resolve_kernel"]["fetch_bytes"] == 2 * 100.0 * 1024                      # coalesced streams: FETCH_SIZE doubled
+    assert len(t["kernel_source_sha256"]) == 64
+
+
 def test_committed_bench_line_keeps_the_contract():
     """The JSON line bench.py printed on the GPU box (profiles/r03_bench_driver_flags.json, the driver's flags): every key
     the bench contract names is there, with the types and relations it asks for; the counters it imports from a committed
