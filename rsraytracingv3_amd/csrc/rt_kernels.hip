@@ -54,11 +54,15 @@ namespace {
                                   // scan recomputes its lane-derived LDS addresses instead of keeping them across the bounce loop)
 #endif
 #ifndef RT_BLOCKS_WAVES_BATCH_WIDE
-#define RT_BLOCKS_WAVES_BATCH_WIDE 6  // ... for scenes whose direction-mask sets take two words (65..128 spheres, the reference's 80
-                                      // slots): 6 / 7 waves 44.4 / 43.6 Grays/s
+#define RT_BLOCKS_WAVES_BATCH_WIDE 7  // ... for scenes whose direction-mask sets take two words (65..128 spheres, the reference's 80
+                                      // slots): 6 / 7 waves 44.4 / 43.6 Grays/s before the tail spill and the phase priorities, 48.5 / 49.0 with them
 #endif
 #ifndef RT_BLOCKS_WAVES_SINGLE
-#define RT_BLOCKS_WAVES_SINGLE 5  // ... and in single-frame launches, several of which are in flight (register count held at the 5-wave step)
+#define RT_BLOCKS_WAVES_SINGLE 7  // ... in sample-only single-frame launches, several of which are in flight: 5 / 6 / 7 waves one frame per
+                                  // launch 47.2 / 44.8 / 46.3 Grays/s before the phase priorities, 47.7 / 44.8 / 48.5 with them
+#endif
+#ifndef RT_BLOCKS_WAVES_FULL
+#define RT_BLOCKS_WAVES_FULL 5    // ... and in launches with per-frame outputs (history in the kernel, diagnostics: 91 registers)
 #endif
 #ifndef RT_X2_PREFETCH
 #define RT_X2_PREFETCH 0  // 1 = request the second random() texel during the scan, 0 = when the hit turns out rough (A/B on one
@@ -2274,8 +2278,8 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
         hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
       }
     } else {
-      if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
-      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, false>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_FULL;
+      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_FULL, false>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
     }
   } else {
     const dim3 blocks((tiles_x + (kTileBlock / 64) - 1) / (kTileBlock / 64), tiles_y, fp.batch);
