@@ -75,8 +75,8 @@ typedef struct rt_stats {
   uint32_t last_stage;        /* render_tiles (variant 0/1): what that launch staged into LDS: 0 nothing, 1 sphere
                                  records, 2 the whole scene image, 3 sphere records + the sphere grid (secondary rays
                                  walk the grid); render_blocks (variant 3): 10 * waves per workgroup + waves per SIMD
-                                 its registers are budgeted for (27 sample-only launches: multi-frame ones and single frames in flight; 25
-                                 launches with per-frame outputs), + 100 when tail_stream followed it (RT_OPT_TAIL_SPILL); 40 for variant 4 */
+                                 its registers are budgeted for (27 multi-frame launches, 25 single frames), + 100 when tail_stream followed
+                                 it (RT_OPT_TAIL_SPILL); 40 for variant 4 */
   uint32_t grid_cells, grid_items; /* the current scene's sphere grid (0 = none: small scene, or not buildable) */
   uint32_t dirmask_cells, dirmask_bins; /* the current scene's direction-mask table (RT_OPT_DIRMASK): cells and direction
                                            bins per cell; 0 = none                                                    */

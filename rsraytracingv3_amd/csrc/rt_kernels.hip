@@ -58,8 +58,10 @@ namespace {
                                       // slots): 6 / 7 waves 44.4 / 43.6 Grays/s before the tail spill and the phase priorities, 48.5 / 49.0 with them
 #endif
 #ifndef RT_BLOCKS_WAVES_SINGLE
-#define RT_BLOCKS_WAVES_SINGLE 7  // ... in sample-only single-frame launches, several of which are in flight: 5 / 6 / 7 waves one frame per
-                                  // launch 47.2 / 44.8 / 46.3 Grays/s before the phase priorities, 47.7 / 44.8 / 48.5 with them
+#define RT_BLOCKS_WAVES_SINGLE 5  // ... in sample-only single-frame launches, several of which are in flight (register count held at the
+                                  // 5-wave step).  5 / 6 / 7 waves, one frame per launch at 8 bounces: 47.2 / 44.8 / 46.3 Grays/s before the
+                                  // phase priorities, 47.7 / 44.8 / 48.5 with them — but 7 against 5 by bounce limit 1 / 2 / 3 / 5 / 8:
+                                  // -14 % / +1.8 % / -1.3 % / -0.3 % / +1.6 % (profiles/r03_ab_waves_with_priorities.txt): level but for the loss
 #endif
 #ifndef RT_BLOCKS_WAVES_FULL
 #define RT_BLOCKS_WAVES_FULL 5    // ... and in launches with per-frame outputs (history in the kernel, diagnostics: 91 registers)
