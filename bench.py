@@ -90,6 +90,10 @@ def main():
     ap.add_argument("--dirmask", type=int, default=-1, help="RT_OPT_DIRMASK: 0 = secondary rays scan every sphere, 1 = direction-mask table (library default)")
     ap.add_argument("--dirmask-k", type=int, default=0, help="RT_OPT_DIRMASK_K (0 = library default)")
     ap.add_argument("--dirmask-cells", type=int, default=0, help="RT_OPT_DIRMASK_CELLS (0 = library default)")
+    ap.add_argument("--dirlist", type=int, default=-1, help="RT_OPT_DIRLIST: candidate lists of scenes with more than 128 spheres (0 = the sphere grid, 1 = library default)")
+    ap.add_argument("--dirlist-k", type=int, default=0, help="RT_OPT_DIRLIST_K (0 = library default)")
+    ap.add_argument("--dirlist-cells", type=int, default=0, help="RT_OPT_DIRLIST_CELLS (0 = library default)")
+    ap.add_argument("--dirlist-reach", type=int, default=0, help="RT_OPT_DIRLIST_REACH (0 = library default)")
     ap.add_argument("--tail-spill", type=int, default=-1,
                     help="RT_OPT_TAIL_SPILL: workgroups with at most this many paths left hand them to the tail kernel (0 = off, -1 = library default)")
     ap.add_argument("--tail-spill-single", type=int, default=-1, help="RT_OPT_TAIL_SPILL_SINGLE: the same for single-frame launches (-1 = library default 0)")
@@ -163,6 +167,14 @@ def main():
         dev.set_option(N.RT_OPT_DIRMASK_K, args.dirmask_k)
     if args.dirmask_cells > 0:
         dev.set_option(N.RT_OPT_DIRMASK_CELLS, args.dirmask_cells)
+    if args.dirlist >= 0:
+        dev.set_option(N.RT_OPT_DIRLIST, args.dirlist)
+    if args.dirlist_k:
+        dev.set_option(N.RT_OPT_DIRLIST_K, args.dirlist_k)
+    if args.dirlist_cells:
+        dev.set_option(N.RT_OPT_DIRLIST_CELLS, args.dirlist_cells)
+    if args.dirlist_reach:
+        dev.set_option(N.RT_OPT_DIRLIST_REACH, args.dirlist_reach)
     if args.tail_spill >= 0:
         dev.set_option(N.RT_OPT_TAIL_SPILL, args.tail_spill)
     if args.tail_spill_single >= 0:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT355_ABI_VERSION 3
+#define RT355_ABI_VERSION 4
 #define RT355_API __attribute__((visibility("default")))
 
 typedef enum rt_status {
@@ -78,8 +78,10 @@ typedef struct rt_stats {
                                  its registers are budgeted for (27 multi-frame launches, 25 single frames), + 100 when tail_stream followed
                                  it (RT_OPT_TAIL_SPILL); 40 for variant 4 */
   uint32_t grid_cells, grid_items; /* the current scene's sphere grid (0 = none: small scene, or not buildable) */
-  uint32_t dirmask_cells, dirmask_bins; /* the current scene's direction-mask table (RT_OPT_DIRMASK): cells and direction
-                                           bins per cell; 0 = none                                                    */
+  uint32_t dirmask_cells, dirmask_bins; /* the current scene's direction-mask table (RT_OPT_DIRMASK) or candidate-list table
+                                           (RT_OPT_DIRLIST): cells and direction bins per cell; 0 = none              */
+  uint32_t dirmask_lists;     /* 0: the table holds bit sets (scenes of up to 128 spheres); otherwise it holds candidate lists
+                                 (larger scenes) and this is the largest reach of an entry, in cells                    */
 } rt_stats;
 
 /* Device-side view of the context's buffers, for zero-copy consumers (RCCL gather,
@@ -342,6 +344,16 @@ enum {
                              * their remaining bounces instead of letting each workgroup bounce its last few paths on in a
                              * mostly empty wave (bit-identical; +5 % at 1080p, +9 % at 3840x2160).  The queue holds at most
                              * workgroups x threshold records (0.33 GB for 8 frames of 1080p); above 4 GiB the threshold shrinks */
+  RT_OPT_DIRLIST = 15,      /* 1 (default): scenes of RT_OPT_DIRLIST_MIN spheres or more (up to 65 535) receive a table of candidate
+                             * LISTS at the next rt_set_scene instead of the sphere grid: [cell of the point a ray has reached][bin of
+                             * its direction] -> up to 15 sphere slots + the distance up to which the list is complete (its reach);
+                             * a ray tests the list and looks the next one up further along when its best hit lies beyond the
+                             * reach.  Such scenes then render in the re-packing shape (3) like the small ones, nothing staged into
+                             * LDS.  0: off (the grid of RT_OPT_GRID_MIN serves).  RT_OPT_DIRMASK = 0 switches both tables off.      */
+  RT_OPT_DIRLIST_MIN = 16,  /* fewest spheres that get candidate lists (default 129: the bit-set table serves up to 128)          */
+  RT_OPT_DIRLIST_CELLS = 17,/* cells the lists' grid aims at (default 16384; cubic cells, at most 128 per axis)                  */
+  RT_OPT_DIRLIST_K = 18,    /* their direction bins per cube-map face edge, 1..16 (default 8: 384 bins)                          */
+  RT_OPT_DIRLIST_REACH = 19,/* the largest reach of an entry, in cells (default 16)                                             */
   RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 1): as RT_OPT_INFLIGHT,
                               each launch staging its samples in a buffer of its own; the history is updated in frame
                               order on the context's stream.  2 hides the resolve pass and the gap between launches
@@ -377,6 +389,27 @@ RT355_API int rt_dirmask_build_host(const float *spheres_xyzr2, uint32_t n_spher
                                     rt_dirmask_info *info, uint64_t *table, size_t table_cap);
 RT355_API int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, const float *origin3,
                                      const float *direction3, uint64_t *mask2, int *served);
+
+/* The candidate lists rt_set_scene builds for scenes of more than 128 spheres (RT_OPT_DIRLIST), exposed for testing them without a
+ * GPU: host code only, the same plan and entry functions the device builder runs.  rt_dirlist_plan_host: the table's geometry and,
+ * in registered_xyzr (n x 4 floats, may be null), the registered balls {c, r_reg}.  rt_dirlist_entry_host: one entry, 8 words =
+ * 16 half-words: h[0] = n << 12 | reach quanta, h[1..n] = sphere slots (a whole table is hundreds of megabytes; the device builds
+ * it).  rt_dirlist_walk_host: one ray through a lane's rounds, entries computed on demand, next to the linear scan of every sphere
+ * in the same arithmetic — the two (key, slot) results must be equal for every ray; *far = 1 when the ray is not served by the table
+ * (the kernels then scan linearly), t_plane = the distance of the ray's plane hit (it ends the rounds like a sphere hit), rounds /
+ * tests = lookups made / spheres tested. */
+typedef struct rt_dirlist_info {
+  uint32_t enabled, nx, ny, nz, k, bins;
+  float bmin[3], bmax[3], cell[3], inv_cell[3], reach_unit, s_cap;
+} rt_dirlist_info;
+RT355_API int rt_dirlist_plan_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t target_cells, uint32_t k,
+                                   uint32_t reach_cells, rt_dirlist_info *info, float *registered_xyzr);
+RT355_API int rt_dirlist_entry_host(const rt_dirlist_info *info, const float *registered_xyzr, uint32_t n_spheres, uint32_t cell,
+                                    uint32_t bin, uint32_t *entry8);
+RT355_API int rt_dirlist_walk_host(const rt_dirlist_info *info, const float *spheres_xyzr2, const float *registered_xyzr,
+                                   uint32_t n_spheres, const float *origin3, const float *direction3, float t_plane,
+                                   uint32_t *listed_key, int32_t *listed_slot, uint32_t *linear_key, int32_t *linear_slot,
+                                   uint32_t *rounds, uint32_t *tests, int *far);
 
 /* Device self-test hooks used by the parity tests: evaluate the device build of the
  * specified math function over n host values (op: 0 sin 1 cos 2 tan 3 asin 4 log2

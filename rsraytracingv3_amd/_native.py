@@ -20,6 +20,7 @@ RT_OPT_INFLIGHT, RT_OPT_GRID_MIN, RT_OPT_BATCH_INFLIGHT = 6, 7, 8
 RT_OPT_DIRMASK, RT_OPT_DIRMASK_MIN, RT_OPT_DIRMASK_CELLS, RT_OPT_DIRMASK_K, RT_OPT_TAIL_SPILL = 9, 10, 11, 12, 13
 RT_TAIL_SPILL_DEFAULT = 32  # kDefaultTailSpill (csrc/rt_device.h)
 RT_OPT_TAIL_SPILL_SINGLE = 14  # default 0
+RT_OPT_DIRLIST, RT_OPT_DIRLIST_MIN, RT_OPT_DIRLIST_CELLS, RT_OPT_DIRLIST_K, RT_OPT_DIRLIST_REACH = 15, 16, 17, 18, 19
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_NOT_READY",
                 -4: "RT_ERR_DEVICE", -5: "RT_ERR_OUT_OF_MEMORY"}
@@ -39,7 +40,7 @@ class RtStats(C.Structure):
                 ("last_wave_iterations", C.c_uint64), ("last_cull_mismatches", C.c_uint64),
                 ("last_resolve_ms", C.c_float), ("last_variant", C.c_uint32), ("last_stage", C.c_uint32),
                 ("grid_cells", C.c_uint32), ("grid_items", C.c_uint32),
-                ("dirmask_cells", C.c_uint32), ("dirmask_bins", C.c_uint32)]
+                ("dirmask_cells", C.c_uint32), ("dirmask_bins", C.c_uint32), ("dirmask_lists", C.c_uint32)]
 
 
 class RtGridInfo(C.Structure):
@@ -52,6 +53,12 @@ class RtDirMaskInfo(C.Structure):
     _fields_ = [("enabled", C.c_uint32), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32), ("k", C.c_uint32),
                 ("bins", C.c_uint32), ("words", C.c_uint32), ("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("cell", C.c_float * 3),
                 ("inv_cell", C.c_float * 3), ("near_min", C.c_float * 3), ("near_max", C.c_float * 3)]
+
+
+class RtDirListInfo(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32), ("k", C.c_uint32),
+                ("bins", C.c_uint32), ("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("cell", C.c_float * 3),
+                ("inv_cell", C.c_float * 3), ("reach_unit", C.c_float), ("s_cap", C.c_float)]
 
 
 class RtDeviceBuffers(C.Structure):
@@ -79,6 +86,11 @@ SIGNATURES = {
     "rt_grid_build_host": (_i, [_vp, _u32, _u32, C.POINTER(RtGridInfo), _vp, _u32, _vp, _u32]),
     "rt_dirmask_build_host": (_i, [_vp, _u32, _u32, _u32, C.POINTER(RtDirMaskInfo), _vp, _sz]),
     "rt_dirmask_lookup_host": (_i, [C.POINTER(RtDirMaskInfo), _vp, _vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    "rt_dirlist_plan_host": (_i, [_vp, _u32, _u32, _u32, _u32, C.POINTER(RtDirListInfo), _vp]),
+    "rt_dirlist_entry_host": (_i, [C.POINTER(RtDirListInfo), _vp, _u32, _u32, _u32, _vp]),
+    "rt_dirlist_walk_host": (_i, [C.POINTER(RtDirListInfo), _vp, _vp, _u32, _vp, _vp, _f, C.POINTER(C.c_uint32), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_int)]),
     "rt_comm_available": (_i, [C.c_char_p, _sz]),
     "rt_comm_get_unique_id": (_i, [_vp]),
     "rt_comm_init": (_i, [_vp, _vp, _u32, _u32, _u32]),

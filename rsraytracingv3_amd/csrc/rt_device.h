@@ -76,6 +76,9 @@ constexpr uint32_t kImageLdsRecords = 1024;  // 16 KB: scenes up to ~300 spheres
 constexpr int kDefaultDirmaskMinSpheres = 26;  // RT_OPT_DIRMASK_MIN
 constexpr int kDefaultDirmaskCells = 4096;     // RT_OPT_DIRMASK_CELLS
 constexpr int kDefaultDirmaskK = 12;           // RT_OPT_DIRMASK_K
+constexpr int kDefaultDirlistCells = 16384;    // RT_OPT_DIRLIST_CELLS: cells aimed at by the candidate lists of large scenes
+constexpr int kDefaultDirlistK = 8;            // RT_OPT_DIRLIST_K: their bins per face edge
+constexpr int kDefaultDirlistReach = 16;       // RT_OPT_DIRLIST_REACH: the largest reach of an entry, in cells
 constexpr int kDefaultGridMinSpheres = 129;    // RT_OPT_GRID_MIN
 constexpr int kDefaultInflight = 4;            // RT_OPT_INFLIGHT
 constexpr int kDefaultBatchInflight = 1;       // RT_OPT_BATCH_INFLIGHT
@@ -203,7 +206,7 @@ constexpr size_t kTailQueueBudget = 4ull << 30;  // bytes of queue a launch may 
 constexpr uint64_t kTailMinTiles = 100000;       // 8x8 tiles from which a launch spills (1080p: 2 frames per launch 42.8 Grays/s without /
                                                  // 41.0 with the spill, 4 frames 47.6 / 48.7, 8 frames 50.2 / 52.2: from three frames up)
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap);
-int tail_blocks_per_cu(size_t lds_bytes);
+int tail_blocks_per_cu(size_t lds_bytes, bool lists);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);
 int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream);
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream,
@@ -223,6 +226,10 @@ int launch_assemble(const AssembleParams &ap, hipStream_t stream);
 int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned long long *masks, hipStream_t stream);
 // fills dm.table ([cells][bins] 64-bit sets) from the n registered spheres reg[] = {c, r_reg} (device memory)
 int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n, unsigned long long *table, hipStream_t stream);
+// fills the candidate-list table of a large scene (dm.lists; [cells][bins] 32-byte entries + the zero entry) from reg[]; *d_overflow
+// (device memory, zeroed by the caller) counts the cells whose near spheres did not fit the builder's list
+int launch_dirlist_build(const DirMaskParams &dm, const float4 *reg, uint32_t n, unsigned long long *table, uint32_t *d_overflow,
+                         hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);
 int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream);
 

@@ -29,8 +29,10 @@
 // disagreements; tests/test_dirmask_host.py checks the sets against the oracle's rays on the CPU.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <vector>
 
 #include "rt_math.h"
 
@@ -51,6 +53,11 @@ struct DirMaskParams {
   float cell[3], inv_cell[3];   // cell edge per axis (equal up to rounding: cubic cells) and its reciprocal
   float near_min[3], near_max[3];
   const unsigned long long *table;  // [cell][bin][words], device memory
+  // candidate LISTS (scenes of more than kDirMaskMaxSpheres spheres; "Candidate lists" below): entries are 32 bytes
+  // (words = 4), `table` holds them
+  uint32_t lists;      // 1: list entries
+  float reach_unit;    // world units per quantum of an entry's reach
+  float s_cap;         // lookups are served for ray parameters up to this; beyond it a ray scans linearly
 };
 
 // Bin of a direction (any non-zero vector): face = 2 * major axis + (major component < 0), (u, v) = the components
@@ -226,6 +233,254 @@ inline DirMaskParams dirmask_plan(const float4 *sph, uint32_t n, uint32_t target
   dm.words = n > 64u ? 2u : 1u;
   dm.entries = dm.nx * dm.ny * dm.nz * dm.bins;
   dm.half_k = 0.5f * static_cast<float>(k);
+  for (uint32_t i = 0; i < n; ++i) reg[i] = make_float4(sph[i].x, sph[i].y, sph[i].z, static_cast<float>(rr[i] * 1.0001));
+  dm.enabled = 1;
+  dm.table = nullptr;
+  return dm;
+}
+
+// ---- Candidate lists: scenes of more than 128 spheres ---------------------------------------------------------------
+// The same table [cell of the ray's origin][bin of its direction], but an entry is a LIST: 16 half-words,
+//     h[0] = n << 12 | q      n <= 15 sphere slots follow in h[1 .. n] (ascending), q = the entry's reach in quanta
+// and it is REACH-LIMITED: it holds every sphere the float test can accept at a distance of up to q * reach_unit from
+// where the ray is looked up — nothing is promised beyond.  A ray is looked up at parameter s (0, or where it enters the box B),
+// tests the entry's spheres — with its true origin and direction, so a sphere gives the same key in whichever round it
+// is tested — and is done when its best hit lies within s + 0.97 * reach; otherwise it moves on by 0.95 * reach and looks
+// the entry of the point it has reached up (or leaves B, and is done).  By induction every sphere accepted at a
+// parameter up to s + reach has been tested after the round at s, so a best hit inside that range is the scan's result: any
+// sphere not yet tested can only be accepted further out.  Dense neighbourhoods get short reaches (the builder cuts an
+// entry's reach until 15 slots suffice), sparse ones long reaches; an entry that cannot be cut to 15 (more than 15
+// registered balls overlap the cell) has q = 0: rays looked up there scan linearly, like every ray the table does not
+// serve (direction not a unit vector, NaN, parameter beyond s_cap).
+//
+// Registered balls.  As for the masks, with two differences.  (1) The rounding and non-unit-direction term of the radius,
+// 0.003 * D, is taken at D_i = 1.01 * (d_cap + r_i) with d_cap = s_cap + the largest reach, instead of at the near
+// box's diagonal: lookups happen at s <= s_cap only, an accepted point lies within reach of the lookup point, so a sphere
+// the float test accepts there has |o - c| <= (s_cap + reach) (1 + 2e-6) + r_reg <= D_i — and a sphere FARTHER from the
+// origin than D_i can only be accepted beyond s + reach ((0.997 D - r) / (1 + 2e-6) > s_cap + reach), where nothing is
+// promised.  In a scene of a thousand small spheres the near box's diagonal would add a third to every radius.  (2) Two
+// exclusion tests instead of one, a sphere is listed unless either proves that no ray of the entry reaches its ball within
+// the reach: the cone of rt_dirmask's masks (bin's angular radius + the cell's half diagonal), and the bin's PYRAMID
+// swept over the cell: for a side plane n of the pyramid (n . d <= 0 for every direction of the grown bin) and any ray
+// point x = o' + t d', n . (x - p) <= n . (o' - p) <= half edge * (|n_x| + |n_y| + |n_z|); likewise behind the cell along the
+// bin's major axis.  The pyramid is what keeps the spheres beside and behind a cell out of its entries (a third fewer
+// candidates on the 1 024-sphere scene, tools/large_scene_model.py).
+constexpr uint32_t kDirListSlots = 15;
+constexpr uint32_t kDirListMaxSpheres = 65535;  // slots are 16-bit
+constexpr uint32_t kDirListMaxDim = 128;        // cells per axis
+constexpr uint32_t kDirListReachQuanta = 4095;  // 12 bits
+constexpr uint32_t kDirListWords = 4;           // 64-bit words per entry
+constexpr float kDirListDone = 0.97f;           // a best hit within s + this * reach ends a ray's scan
+constexpr float kDirListStep = 0.95f;           // otherwise the next lookup is this * reach further on
+
+// What the builder needs of one (cell, bin): the cell's centre and extents (with slack), the bin's centre direction,
+// cos / sin of its angular radius (grown), and the pyramid's four side planes.
+struct DirListGeom {
+  f3 p, a;
+  float h, he, ct, st;
+  f3 n[4];
+  float support[4];
+  uint32_t axis;
+  float sign;
+};
+
+RT_HD DirListGeom dirlist_geometry(const DirMaskParams &dm, uint32_t cell, uint32_t bin) {
+  DirListGeom g;
+  const uint32_t ix = cell % dm.nx, iy = (cell / dm.nx) % dm.ny, iz = cell / (dm.nx * dm.ny);
+  g.p = mk3(dm.bmin[0] + (static_cast<float>(ix) + 0.5f) * dm.cell[0], dm.bmin[1] + (static_cast<float>(iy) + 0.5f) * dm.cell[1],
+            dm.bmin[2] + (static_cast<float>(iz) + 0.5f) * dm.cell[2]);
+  const float edge = fmaxf(fmaxf(dm.cell[0], dm.cell[1]), dm.cell[2]);
+  const float box = fmaxf(fmaxf(dm.bmax[0] - dm.bmin[0], dm.bmax[1] - dm.bmin[1]), dm.bmax[2] - dm.bmin[2]);
+  // slack for the rounding of the lookup point o + s d (a few ulp of coordinates of the box's size: ~1e-7 box) and of its cell index
+  const float slack = 1e-4f * box;
+  g.he = 0.5f * edge * 1.01f + slack;
+  g.h = g.he * 1.7320509f * 1.0001f;
+  const uint32_t k = dm.k;
+  const uint32_t bu = bin % k, bv = (bin / k) % k, face = bin / (k * k);
+  g.axis = face >> 1;
+  g.sign = (face & 1u) ? -1.0f : 1.0f;
+  const float step = 2.0f / static_cast<float>(k), grow = 0.02f * step + 1e-4f;
+  const float u0 = -1.0f + step * static_cast<float>(bu) - grow, u1 = -1.0f + step * static_cast<float>(bu + 1u) + grow;
+  const float v0 = -1.0f + step * static_cast<float>(bv) - grow, v1 = -1.0f + step * static_cast<float>(bv + 1u) + grow;
+  const uint32_t a0 = g.axis, a1 = (g.axis + 1u) % 3u, a2 = (g.axis + 2u) % 3u;
+  const float sign = g.sign;
+  auto vec = [&](float c0, float c1, float c2) {  // components along (major axis, u axis, v axis)
+    float c[3];
+    c[a0] = c0;
+    c[a1] = c1;
+    c[a2] = c2;
+    return mk3(c[0], c[1], c[2]);
+  };
+  auto unit = [&](f3 v) {
+    const float inv = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    return mk3(v.x * inv, v.y * inv, v.z * inv);
+  };
+  g.a = unit(vec(sign, 0.5f * (u0 + u1), 0.5f * (v0 + v1)));
+  {
+    const f3 c00 = unit(vec(sign, u0, v0)), c01 = unit(vec(sign, u0, v1)), c10 = unit(vec(sign, u1, v0)), c11 = unit(vec(sign, u1, v1));
+    const f3 a = g.a;
+    float cos_theta = fminf(fminf(a.x * c00.x + a.y * c00.y + a.z * c00.z, a.x * c01.x + a.y * c01.y + a.z * c01.z),
+                            fminf(a.x * c10.x + a.y * c10.y + a.z * c10.z, a.x * c11.x + a.y * c11.y + a.z * c11.z));
+    cos_theta = fminf(cos_theta, 1.0f);
+    const float sin_theta0 = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    g.ct = cos_theta * 0.999998f - sin_theta0 * 2e-3f;  // cos / sin of theta + 2e-3
+    g.st = sin_theta0 * 0.999998f + cos_theta * 2e-3f;
+  }
+  // side planes: u = d_u / |d_major| <= u1  <=>  d_u - u1 sign d_major <= 0, and so on
+  g.n[0] = unit(vec(-u1 * sign, 1.0f, 0.0f));
+  g.n[1] = unit(vec(u0 * sign, -1.0f, 0.0f));
+  g.n[2] = unit(vec(-v1 * sign, 0.0f, 1.0f));
+  g.n[3] = unit(vec(v0 * sign, 0.0f, -1.0f));
+  for (int j = 0; j < 4; ++j) g.support[j] = g.he * (fabsf(g.n[j].x) + fabsf(g.n[j].y) + fabsf(g.n[j].z)) * 1.0001f;
+  return g;
+}
+
+// Can a ray of the entry be accepted by the sphere {c, r_reg} at all — and if so, `dmin`: a lower bound of the distance
+// from the ray's lookup point to any point of the registered ball.  NaN anywhere -> yes, at distance 0.
+RT_HD bool dirlist_candidate(const DirListGeom &g, float4 reg, float &dmin) {
+  const float vx = reg.x - g.p.x, vy = reg.y - g.p.y, vz = reg.z - g.p.z;
+  const float l2 = vx * vx + vy * vy + vz * vz;
+  const float R = reg.w + g.h;
+  dmin = 0.0f;
+  if (!(l2 > R * R * 1.0001f)) return true;  // the cell (grown) touches the registered ball; NaN -> in
+  const float l = sqrtf(l2);
+  {  // the bin's cone
+    const float inv_l = 1.0f / l;
+    const float s = fminf(R * inv_l * 1.0001f, 1.0f);
+    const float c = sqrtf(fmaxf(1.0f - s * s, 0.0f));
+    const float cos_sum = g.ct * c - g.st * s;
+    const float cos_ang = (g.a.x * vx + g.a.y * vy + g.a.z * vz) * inv_l;
+    if (cos_ang < cos_sum - 1e-4f) return false;
+  }
+  // the bin's pyramid swept over the cell; the margin covers the rounding of the dot products (1e-6 of the box at most)
+  const float margin = reg.w * 1.0001f + 1e-5f * l;
+  for (int j = 0; j < 4; ++j)
+    if (g.n[j].x * vx + g.n[j].y * vy + g.n[j].z * vz > g.support[j] + margin) return false;
+  const float along = g.axis == 0u ? vx : (g.axis == 1u ? vy : vz);
+  if (-g.sign * along > g.he + margin) return false;  // behind the cell along the major axis
+  dmin = fmaxf(l * 0.9999f - R, 0.0f);
+  return true;
+}
+
+// One list entry from the registered spheres recs[0 .. count) = {c, r_reg}; their slots are slot[j], or j when `slot` is
+// null (ascending either way).  Host and device run this same function; the device hands in the spheres near the cell only
+// (those with dmin <= the largest reach: the others cannot be listed).
+RT_HD void dirlist_entry(const DirMaskParams &dm, uint32_t cell, uint32_t bin, const float4 *recs, const uint16_t *slot, uint32_t count,
+                         uint32_t out[8]) {
+  const DirListGeom g = dirlist_geometry(dm, cell, bin);
+  auto listed_within = [&](float reach) {  // candidates a ray can be accepted by within `reach`
+    uint32_t c = 0;
+    for (uint32_t j = 0; j < count; ++j) {
+      float dmin;
+      if (dirlist_candidate(g, recs[j], dmin) && dmin <= reach) c += 1u;
+    }
+    return c;
+  };
+  uint32_t q = kDirListReachQuanta;
+  if (listed_within(dm.reach_unit * static_cast<float>(q)) > kDirListSlots) {
+    // the largest reach that lists at most 15: bisection over the quanta (q = 0: none does — the entry serves no ray)
+    uint32_t lo = 0u, hi = q;  // count(hi) > 15; lo = 0 stands for "unserved"
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (listed_within(dm.reach_unit * static_cast<float>(mid)) <= kDirListSlots) lo = mid;
+      else hi = mid;
+    }
+    q = lo;
+  }
+  for (int w = 0; w < 8; ++w) out[w] = 0u;
+  if (q == 0u) return;  // n = 0, q = 0
+  const float reach = dm.reach_unit * static_cast<float>(q);
+  uint32_t n = 0;
+  for (uint32_t j = 0; j < count; ++j) {
+    float dmin;
+    if (dirlist_candidate(g, recs[j], dmin) && dmin <= reach) {
+      const uint32_t s = slot ? static_cast<uint32_t>(slot[j]) : j;
+      const uint32_t hw = 1u + n;  // half-word index
+      out[hw >> 1] |= s << (16u * (hw & 1u));
+      n += 1u;
+    }
+  }
+  out[0] |= (n << 12) | q;
+}
+
+// Host side: resolution, boxes and registered radii for n spheres {cx, cy, cz, r*r}; reg[i] receives {c, r_reg}.  Returns a
+// disabled plan for scenes the lists do not serve (no sphere, more than 65 535, non-finite data).
+inline DirMaskParams dirlist_plan(const float4 *sph, uint32_t n, uint32_t target_cells, uint32_t k, uint32_t reach_cells, float4 *reg) {
+  DirMaskParams dm{};
+  if (n == 0 || n > kDirListMaxSpheres || k < 1 || k > kDirMaskMaxK || target_cells < 1 || reach_cells < 1) return dm;
+  double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  std::vector<double> r(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    const double c[3] = {sph[i].x, sph[i].y, sph[i].z};
+    if (!(sph[i].w >= 0.0f) || !std::isfinite(sph[i].w) || !std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) return dm;
+    r[i] = std::sqrt(static_cast<double>(sph[i].w));
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = std::fmin(lo[a], c[a] - r[i]);
+      hi[a] = std::fmax(hi[a], c[a] + r[i]);
+    }
+  }
+  const double diag = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+  if (!(diag > 0.0) || !std::isfinite(diag) || diag > 1e15) return dm;
+  std::vector<double> sorted(r);
+  std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+  const double r_med = sorted[n / 2];
+  // d_cap: how far from a ray's origin the table is asked about spheres (s_cap + the largest reach).  A hundred median
+  // radii keep the rounding term of the registered radius (0.003 d_cap) below a third of a typical radius.
+  const double d_cap = std::fmin(2.0 * diag, std::fmax(100.0 * r_med, 0.5 * diag));
+  const double reach_bound = 0.3 * d_cap, s_cap = 0.7 * d_cap;
+  std::vector<double> rr(n);
+  double glo[3], ghi[3], ext[3], edge = 0.0;
+  uint32_t dims[3] = {1, 1, 1};
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int a = 0; a < 3; ++a) {
+      glo[a] = INFINITY;
+      ghi[a] = -INFINITY;
+    }
+    for (uint32_t i = 0; i < n; ++i) {
+      const double eps = 0.003 * 1.01 * (d_cap + r[i]);
+      rr[i] = 1.001 * std::sqrt(r[i] * r[i] + eps * eps) + 1e-3 * edge;
+      const double c[3] = {sph[i].x, sph[i].y, sph[i].z};
+      for (int a = 0; a < 3; ++a) {
+        glo[a] = std::fmin(glo[a], c[a] - rr[i]);
+        ghi[a] = std::fmax(ghi[a], c[a] + rr[i]);
+      }
+    }
+    double bdiag = 0.0;
+    for (int a = 0; a < 3; ++a) bdiag += (ghi[a] - glo[a]) * (ghi[a] - glo[a]);
+    bdiag = std::sqrt(bdiag);
+    for (int a = 0; a < 3; ++a) {
+      glo[a] -= 1e-3 * bdiag;
+      ghi[a] += 1e-3 * bdiag;
+      ext[a] = ghi[a] - glo[a];
+    }
+    edge = std::cbrt(ext[0] * ext[1] * ext[2] / static_cast<double>(target_cells));
+    for (int a = 0; a < 3; ++a) {
+      const double want = edge > 0.0 ? ext[a] / edge : 1.0;
+      dims[a] = static_cast<uint32_t>(std::fmin(static_cast<double>(kDirListMaxDim), std::fmax(1.0, std::ceil(want - 1e-9))));
+    }
+    edge = 0.0;
+    for (int a = 0; a < 3; ++a) edge = std::fmax(edge, ext[a] / dims[a]);
+  }
+  for (int a = 0; a < 3; ++a) {
+    dm.bmin[a] = static_cast<float>(glo[a]);
+    dm.bmax[a] = static_cast<float>(ghi[a]);
+    dm.cell[a] = static_cast<float>(edge);
+    dm.inv_cell[a] = static_cast<float>(1.0 / edge);
+    dm.near_min[a] = -INFINITY;  // (the lists bound a ray's distance by s_cap instead of a near box)
+    dm.near_max[a] = INFINITY;
+  }
+  dm.nx = dims[0];
+  dm.ny = dims[1];
+  dm.nz = dims[2];
+  dm.k = k;
+  dm.bins = 6u * k * k;
+  dm.words = kDirListWords;
+  dm.entries = dm.nx * dm.ny * dm.nz * dm.bins;
+  dm.half_k = 0.5f * static_cast<float>(k);
+  dm.lists = 1;
+  const double reach = std::fmin(static_cast<double>(reach_cells) * edge, reach_bound);
+  dm.reach_unit = static_cast<float>(reach / static_cast<double>(kDirListReachQuanta) * (1.0 - 1e-6));
+  dm.s_cap = static_cast<float>(s_cap);
   for (uint32_t i = 0; i < n; ++i) reg[i] = make_float4(sph[i].x, sph[i].y, sph[i].z, static_cast<float>(rr[i] * 1.0001));
   dm.enabled = 1;
   dm.table = nullptr;

@@ -57,6 +57,9 @@ namespace {
 #define RT_BLOCKS_WAVES_BATCH_WIDE 7  // ... for scenes whose direction-mask sets take two words (65..128 spheres, the reference's 80
                                       // slots): 6 / 7 waves 44.4 / 43.6 Grays/s before the tail spill and the phase priorities, 48.5 / 49.0 with them
 #endif
+#ifndef RT_BLOCKS_WAVES_LISTS
+#define RT_BLOCKS_WAVES_LISTS 6   // ... for large scenes (candidate lists; nothing staged into LDS)
+#endif
 #ifndef RT_BLOCKS_WAVES_SINGLE
 #define RT_BLOCKS_WAVES_SINGLE 5  // ... in sample-only single-frame launches, several of which are in flight (register count held at the
                                   // 5-wave step).  5 / 6 / 7 waves, one frame per launch at 8 bounces: 47.2 / 44.8 / 46.3 Grays/s before the
@@ -108,6 +111,10 @@ constexpr uint32_t kXchgPaths = RT_XCHG_PATHS;  // paths the block kernel's LDS 
 // Per-wave LDS scratch of the balanced direction-mask scan: 64 rays (float4 + float2), 64 best hits (u64), kPairCap pairs (u16).
 constexpr uint32_t kPairCap = 512;
 constexpr uint32_t kScanScratchBytes = 64u * 16u + 64u * 8u + 64u * 8u + kPairCap * 2u;  // 3072
+// ... of the candidate-LIST scan of large scenes (rt_dirmask.h "Candidate lists"): 64 rays, 64 best hits, the 64 lanes' 32-byte
+// entries as loaded, and up to 64 x 15 (lane, position) pairs
+constexpr uint32_t kListPairCap = 64u * kDirListSlots;
+constexpr uint32_t kListScratchBytes = 64u * 16u + 64u * 8u + 64u * 8u + 64u * 32u + kListPairCap * 2u;  // 6016
 constexpr uint32_t kXchgBytes = kXchgPaths * (RT_PACK_HITS ? 5u : 4u) * 16u;
 // With two waves per workgroup the scratch may share the exchange buffer's LDS: the buffer is only written after a count
 // barrier that both waves reach after their scans, and once it has been used a single wave is left.  Other workgroup sizes
@@ -116,6 +123,8 @@ constexpr bool kScratchInXchg = RT_BLOCK_NW == 2;
 constexpr uint32_t kBlocksLdsExtra = !RT_BALANCED_SCAN ? kXchgBytes
                                      : (kScratchInXchg ? (kXchgBytes > RT_BLOCK_NW * kScanScratchBytes ? kXchgBytes : RT_BLOCK_NW * kScanScratchBytes)
                                                        : kXchgBytes + RT_BLOCK_NW * kScanScratchBytes);
+constexpr uint32_t kBlocksLdsExtraLists = kScratchInXchg ? (kXchgBytes > RT_BLOCK_NW * kListScratchBytes ? kXchgBytes : RT_BLOCK_NW * kListScratchBytes)
+                                                         : kXchgBytes + RT_BLOCK_NW * kListScratchBytes;
 
 // Correctly rounded sqrt for x >= 2^-96 (also +0, +inf, NaN): v_sqrt_f32 is within 1 ulp, so
 // the IEEE result is one of {s-1ulp, s, s+1ulp}; the signs of the two fused residuals pick it
@@ -658,7 +667,8 @@ __device__ __forceinline__ bool scan_spheres_balanced(const float4 *__restrict__
       const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
       if (fminf(q, -dn) >= 0.0f) {
         const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;
-        atomicMin(&best[owner], (static_cast<unsigned long long>(key) << 32) | i);
+        // strictly below the initial distance, as the linear scan's '<' (ray.hlsl:98): a key of exactly kNoHitKey is no hit
+        if (key < kNoHitKey) atomicMin(&best[owner], (static_cast<unsigned long long>(key) << 32) | i);
       }
     }
   }
@@ -855,6 +865,162 @@ __device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const Frame
   return alive ? merge_sphere_hit(sv, hp, sh) : miss;
 }
 
+// ---- candidate lists (rt_dirmask.h "Candidate lists"): secondary rays of scenes with more than 128 spheres ------------
+// ray_intersect's sphere part for a whole wave (every lane calls it; `alive` = the lane carries a ray) in ROUNDS: every
+// ray that is not done looks the entry of the point it has reached up (32 bytes: up to 15 sphere slots and the entry's
+// reach), the wave tests all its (ray, sphere) pairs 64 at a time — whichever lane a pair falls to reads ray and slot from
+// LDS, the sphere record from memory, and a pair that hits does an LDS atomic min of (key << 32 | slot) on its ray's word:
+// the lexicographic (key, slot) minimum, i.e. the linear scan's strict '<' in ascending slot order — and a ray whose
+// best hit (sphere or plane) lies inside the reach is done; the others advance and look up again.  Rays the table does
+// not serve (direction not a unit vector, NaN, farther along than s_cap, an entry without a reach) scan linearly at the end,
+// together (the cooperative scan when they are few).  The planes are tested under the first round's load.
+// `scratch_base`: kListScratchBytes per wave.
+template <bool LEAN>
+__device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const FrameParams &fp, f3 o, f3 d, bool alive, Hit miss,
+                                                unsigned char *scratch_base) {
+  const DirMaskParams &dm = *sv.dm;
+  uint32_t tid = threadIdx.x;
+  asm volatile("; thread index re-read per scan" : "+v"(tid));
+  const uint32_t lane = tid & 63u;
+  unsigned char *scratch = scratch_base + (tid >> 6) * kListScratchBytes;
+  float4 *rays_a = reinterpret_cast<float4 *>(scratch);
+  float2 *rays_b = reinterpret_cast<float2 *>(scratch + 64u * 16u);
+  unsigned long long *best = reinterpret_cast<unsigned long long *>(scratch + 64u * 24u);
+  uint4 *raw = reinterpret_cast<uint4 *>(scratch + 64u * 32u);
+  const uint16_t *raw16 = reinterpret_cast<const uint16_t *>(raw);
+  uint16_t *pairs = reinterpret_cast<uint16_t *>(scratch + 64u * 64u);
+  RT_CNT(4, 1)
+  const bool unit = fabsf(dot3(d, d) - 1.0f) <= 4e-6f;  // false for a NaN in d
+  const bool inside = (o.x >= dm.bmin[0]) & (o.x <= dm.bmax[0]) & (o.y >= dm.bmin[1]) & (o.y <= dm.bmax[1]) & (o.z >= dm.bmin[2]) &
+                      (o.z <= dm.bmax[2]);  // false for a NaN in o
+  bool todo = alive & unit;  // still looking entries up
+  bool far = alive & !unit;  // scans linearly at the end
+  float s = 0.0f;            // ray parameter of the next lookup
+  if (__builtin_amdgcn_ballot_w64(todo & !inside) != 0ull) {
+    // rays that start outside the box of the registered balls continue from the point where they enter it; a ray that
+    // misses it meets no sphere.  A NaN origin fails every compare below: the ray ends up `far`.
+    const float big = 1e30f;
+    const float ivx = fabsf(d.x) > 1e-30f ? __builtin_amdgcn_rcpf(d.x) : (d.x < 0.0f ? -big : big);
+    const float ivy = fabsf(d.y) > 1e-30f ? __builtin_amdgcn_rcpf(d.y) : (d.y < 0.0f ? -big : big);
+    const float ivz = fabsf(d.z) > 1e-30f ? __builtin_amdgcn_rcpf(d.z) : (d.z < 0.0f ? -big : big);
+    const float ax = (dm.bmin[0] - o.x) * ivx, bx = (dm.bmax[0] - o.x) * ivx;
+    const float ay = (dm.bmin[1] - o.y) * ivy, by = (dm.bmax[1] - o.y) * ivy;
+    const float az = (dm.bmin[2] - o.z) * ivz, bz = (dm.bmax[2] - o.z) * ivz;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const bool outside = todo & !inside;
+    const bool finite = (o.x == o.x) & (o.y == o.y) & (o.z == o.z);
+    const bool misses = outside & finite & !(t_in <= t_out);
+    const bool beyond = outside & (!finite | (t_in > dm.s_cap));  // (a NaN t_in with a finite origin cannot happen: d is a unit vector)
+    s = outside ? t_in : 0.0f;
+    far |= beyond;
+    todo &= !misses & !beyond;
+  }
+  const float inv_major = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
+  const uint32_t bin = dirmask_bin(d, inv_major, dm.k, dm.half_k);
+  rays_a[lane] = make_float4(o.x, o.y, o.z, d.x);
+  rays_b[lane] = make_float2(d.y, d.z);
+  best[lane] = (static_cast<unsigned long long>(kNoHitKey) << 32) | 0xffffffffull;
+  Hit hp = miss;
+  bool planes_pending = true;
+  const uint4 *table = reinterpret_cast<const uint4 *>(dm.table);
+  for (uint32_t round = 0u; __builtin_amdgcn_ballot_w64(todo) != 0ull; ++round) {
+    if (round == 48u) {  // rays that crawl through entries of tiny reaches (heaps of overlapping balls): the linear scan serves them
+      far |= todo;
+      break;
+    }
+    const f3 p = fma3(d, s, o);
+    const uint32_t entry = todo ? dirmask_cell(dm, p) * dm.bins + bin : dm.entries;  // lanes without a lookup read the zero entry
+    const uint4 w0 = table[2u * static_cast<size_t>(entry)], w1 = table[2u * static_cast<size_t>(entry) + 1u];
+    if (planes_pending) {  // wave-uniform: the first round
+      if (alive) hp = nearest_plane(sv, o, d);
+      planes_pending = false;
+    }
+    raw[2u * lane] = w0;
+    raw[2u * lane + 1u] = w1;
+    const uint32_t n = todo ? (w0.x >> 12) & 15u : 0u;
+    const uint32_t q = w0.x & 0xfffu;
+    const uint32_t incl = wave_inclusive_sum(n);
+    const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    RT_CNT(5, (total + 63u) >> 6)
+    RT_CNT_LANE(6, n)
+    {
+      uint16_t *mine = pairs + (incl - n);
+      const uint32_t tag = lane << 8;
+      for (uint32_t j = 0; j < n; ++j) mine[j] = static_cast<uint16_t>(tag | (j + 1u));
+    }
+    // LDS operations of one wave are carried out in the order they were issued; the fences only keep the compiler from moving
+    // the reads below above the writes of other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t first = 0u; first < total; first += 64u) {  // wave-uniform trip count
+      const uint32_t j = first + lane;
+      if (j < total) {
+        const uint32_t pr = pairs[j];
+        const uint32_t owner = pr >> 8;
+        const uint32_t i = raw16[owner * 16u + (pr & 255u)];
+        const float4 ra = rays_a[owner];
+        const float2 rb = rays_b[owner];
+        const float4 g = sv.sph[i];
+        const float nx = ra.x - g.x, ny = ra.y - g.y, nz = ra.z - g.z;
+        const float dn = fmaf(rb.y, nz, fmaf(rb.x, ny, ra.w * nx));
+        const float qd = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
+        if (fminf(qd, -dn) >= 0.0f) {
+          const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(qd)) - kEpsBits;
+          if (key < kNoHitKey) atomicMin(&best[owner], (static_cast<unsigned long long>(key) << 32) | i);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (todo) {
+      const uint32_t key = static_cast<uint32_t>(best[lane] >> 32);
+      const float t_sphere = __uint_as_float(key + kEpsBits);  // 1e6 when nothing has hit: beyond any reach that matters
+      const float t_near = hp.obj >= 0 ? fminf(hp.t, t_sphere) : t_sphere;
+      const float reach = static_cast<float>(q) * dm.reach_unit;
+      if (q == 0u) {  // the entry serves no ray (too many overlapping balls)
+        far = true;
+        todo = false;
+      } else if (t_near <= fmaf(reach, kDirListDone, s)) {
+        todo = false;  // every sphere not tested yet can only be accepted beyond s + reach
+      } else {
+        s = fmaf(reach, kDirListStep, s);
+        const f3 pn = fma3(d, s, o);
+        const bool in_box = (pn.x >= dm.bmin[0]) & (pn.x <= dm.bmax[0]) & (pn.y >= dm.bmin[1]) & (pn.y <= dm.bmax[1]) &
+                            (pn.z >= dm.bmin[2]) & (pn.z <= dm.bmax[2]);
+        if (!in_box) todo = false;  // left the box of the registered balls (it is convex: the ray does not come back)
+        else if (s > dm.s_cap) {
+          far = true;
+          todo = false;
+        }
+      }
+    }
+  }
+  if (planes_pending && alive) hp = nearest_plane(sv, o, d);  // no lane looked anything up
+  SphereHit sh;
+  {
+    const unsigned long long res = best[lane];
+    sh.key = static_cast<uint32_t>(res >> 32);
+    sh.slot = static_cast<int>(static_cast<uint32_t>(res));  // 0xffffffff = -1: nothing hit
+  }
+  const unsigned long long far_mask = __builtin_amdgcn_ballot_w64(far);
+  if (far_mask != 0ull) {  // rays the table does not serve: the linear scan (its result stands alone: it tests every sphere)
+    asm volatile("; rare path: rays outside the candidate lists' domain" ::: "memory");
+    const uint32_t n_far = static_cast<uint32_t>(__popcll(far_mask));
+    SphereHit lin{kNoHitKey, -1};
+    if (n_far <= 32u) lin = scan_spheres_coop(sv.sph, sv.n_sph_pad, o, d, far, far_mask, n_far);
+    else if (far) lin = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
+    if (far) sh = lin;
+  }
+  if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
+    const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
+    if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
+  }
+  return alive ? merge_sphere_hit(sv, hp, sh) : miss;
+}
+
 // State of one pixel's path between two iterations of frag.hlsl:36-43.
 struct Path {
   f3 o, d, energy, result;
@@ -951,11 +1117,14 @@ __device__ __forceinline__ bool path_shade(const SceneView &sv, const FrameParam
 // lane carries a ray).  The first random() texel is requested before the scan and used after it if the hit is
 // rough: the gather's latency (an L2 round trip) hides under the object scan.  Picks the
 // wave-cooperative scan when at most 32 lanes are live.  Returns the lane's new `alive`.
-template <bool DEFER_SKY, bool GRID = false, bool LEAN = false>
+// MODE: how secondary rays find their spheres — 0 the direction-mask table of small scenes (or the linear / cooperative scan), 1 the
+// walk through the sphere grid, 2 the candidate lists of large scenes (`scratch`: kListScratchBytes per wave).
+template <bool DEFER_SKY, int MODE = 0, bool LEAN = false>
 __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameParams &fp, Path &s, bool alive,
                                                const unsigned long long *__restrict__ primary_mask,
                                                const unsigned long long *__restrict__ primary_mask2 RT_PH_PARAMS,
-                                               const GridParams *gp = nullptr) {
+                                               const GridParams *gp = nullptr, unsigned char *scratch = nullptr) {
+  constexpr bool GRID = MODE == 1;
   const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
   const uint32_t n_live = static_cast<uint32_t>(__popcll(live));
   if (n_live == 0u) return false;
@@ -1001,6 +1170,18 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
     RT_REQUEST_X2
     if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
     RT_PH_MARK(3)
+  } else if (MODE == 2) {
+    // secondary rays of a large scene: candidate lists, in rounds (rt_dirmask.h)
+    Hit miss;
+    miss.t = 0.0f;
+    miss.obj = -1;
+    miss.slot = -1;
+    miss.plane = false;
+    const Hit h = intersect_listed<LEAN>(sv, fp, s.o, s.d, alive, miss, scratch);
+    RT_PH_MARK(1)
+    RT_REQUEST_X2
+    if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, h, x1, x2, seed1);
+    RT_PH_MARK(3)
   } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
     // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
     Hit miss;
@@ -1043,7 +1224,7 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
 // for — the tile's culled list for primary rays, the cooperative scan at <= 32 live rays, the full scan otherwise — and
 // the planes.  `alive` lanes get their Hit (obj -1 = miss); the others get a miss.  Used by render_blocks, which packs the
 // paths that HIT before it shades them.
-template <bool LEAN>
+template <bool LEAN, bool LISTS = false>
 __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FrameParams &fp, const Path &s, bool alive,
                                               const unsigned long long *__restrict__ primary_mask,
                                               const unsigned long long *__restrict__ primary_mask2, unsigned char *scratch RT_PH_PARAMS) {
@@ -1065,6 +1246,10 @@ __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FramePa
       h = finish_hit(sv, sh, s.o, s.d);
     }
     RT_PH_MARK(0)
+  } else if (LISTS) {
+    // secondary rays of a large scene: candidate lists, in rounds (rt_dirmask.h)
+    h = intersect_listed<LEAN>(sv, fp, s.o, s.d, alive, h, scratch);
+    RT_PH_MARK(1)
   } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
     // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
     h = intersect_masked<LEAN>(sv, fp, s.o, s.d, alive, entry, h, scratch);
@@ -1181,14 +1366,15 @@ __device__ __forceinline__ TilePos grid_tile_pos() {
 
 // STAGE: 2 = the whole scene image staged into LDS, 1 = only the sphere records (scenes of hundreds of
 // spheres), 3 = the sphere records and the sphere grid (secondary rays walk the grid), 0 = nothing (scenes
-// beyond a workgroup's LDS): everything else is read from global memory.
+// beyond a workgroup's LDS): everything else is read from global memory; 4 = nothing staged, secondary rays use the candidate
+// lists of large scenes (LDS holds the waves' scan scratch).
 // THREADS: 256, or 128 where the staged data is small enough for 128-thread workgroups to fill a CU's wave slots
 // (a workgroup holds its LDS until its slowest wave ends: smaller groups drain faster — +10 % at 256 spheres —
 // but at 1 024 spheres 28 KB per group would leave a CU with 10 waves instead of 20).
 template <int STAGE, int THREADS = kTileBlock>
 __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_image[];
-  if (STAGE != 0) {
+  if (STAGE != 0 && STAGE != 4) {
     const uint32_t n = STAGE == 2 ? sc.image_records : sc.n_sph_pad;
     for (uint32_t i = threadIdx.x; i < n; i += THREADS) lds_image[i] = sc.image[i];
     if (STAGE == 3) {  // the grid's cell table and item list, straight behind the sphere records
@@ -1197,7 +1383,9 @@ __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FramePar
     }
     __syncthreads();
   }
-  SceneView sv = make_view(sc, STAGE != 0 ? lds_image : sc.image, STAGE == 2 ? lds_image : sc.image);
+  SceneView sv = make_view(sc, (STAGE != 0 && STAGE != 4) ? lds_image : sc.image, STAGE == 2 ? lds_image : sc.image);
+  unsigned char *scratch = STAGE == 4 ? reinterpret_cast<unsigned char *>(lds_image) : nullptr;
+  constexpr int MODE = STAGE == 3 ? 1 : (STAGE == 4 ? 2 : 0);
   if (STAGE == 3) {
     sv.grid_cells = reinterpret_cast<const uint32_t *>(lds_image + sc.n_sph_pad);
     sv.grid_items = reinterpret_cast<const uint16_t *>(lds_image + sc.n_sph_pad + (sc.grid.off_items - sc.grid.off_cells));
@@ -1222,11 +1410,10 @@ __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FramePar
     alive = fp.reflection_limit != 0u;
   }
   if (fp.tile_masks != nullptr && __builtin_amdgcn_ballot_w64(alive) != 0ull)
-    alive = path_step_wave<true, STAGE == 3>(sv, fp, s, alive, fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words,
-                                             fp.tile_masks + static_cast<size_t>(tiles_x + tp.row) * fp.mask_words RT_PH_ARGS,
-                                             &sc.grid);
+    alive = path_step_wave<true, MODE>(sv, fp, s, alive, fp.tile_masks + static_cast<size_t>(tp.col) * fp.mask_words,
+                                       fp.tile_masks + static_cast<size_t>(tiles_x + tp.row) * fp.mask_words RT_PH_ARGS, &sc.grid, scratch);
   while (__builtin_amdgcn_ballot_w64(alive) != 0ull)
-    alive = path_step_wave<true, STAGE == 3>(sv, fp, s, alive, nullptr, nullptr RT_PH_ARGS, &sc.grid);
+    alive = path_step_wave<true, MODE>(sv, fp, s, alive, nullptr, nullptr RT_PH_ARGS, &sc.grid, scratch);
   if (valid) {
     path_end<true>(fp, s);
     seg = s.seg;
@@ -1244,7 +1431,10 @@ __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FramePar
 // most of a tile's later scans run with a handful of live lanes.  Pixel results do not depend on which
 // lane finishes a path, so the frame stays bit-identical.  (RT_PACK_HITS 0: count and pack the survivors after
 // the shading instead.)
-template <int NW, int WAVES, bool LEAN, bool SPILL = false>
+// LISTS: a large scene — nothing is staged (records and materials come from memory through the vector cache: a thousand spheres'
+// records alone would cost the workgroups their occupancy), secondary rays use the candidate lists; LDS holds the exchange buffer
+// and the two waves' list-scan scratch.
+template <int NW, int WAVES, bool LEAN, bool SPILL = false, bool LISTS = false>
 __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, FrameParams fp) {
   extern __shared__ float4 lds_all[];
   // The single-frame form (WAVES = 5) overlaps with its neighbours' launches and runs best at 5 waves per SIMD (A/B on
@@ -1258,12 +1448,13 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   // (program order), so no write can pass a read of the value it replaces — also on iterations that
   // do not pack and therefore have no second barrier.
   __shared__ unsigned int wave_count[2][NW];
-  float4 *xchg = lds_all + sc.image_records;  // kXchgPaths paths x 4 float4, behind the staged scene image
+  float4 *xchg = lds_all + (LISTS ? 0u : sc.image_records);  // kXchgPaths paths x 4 float4, behind the staged scene image
   // the waves' scratch for the balanced direction-mask scan (shares the exchange buffer's LDS when NW == 2: kScratchInXchg);
-  // wave w's part starts w * kScanScratchBytes in
+  // wave w's part starts w * kScanScratchBytes (kListScratchBytes) in
   unsigned char *scratch = reinterpret_cast<unsigned char *>(xchg) + (kScratchInXchg ? 0u : kXchgBytes);
-  for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
-  const SceneView sv = make_view(sc, lds_all, lds_all);
+  if (!LISTS)
+    for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
+  const SceneView sv = LISTS ? make_view(sc, sc.image, sc.image) : make_view(sc, lds_all, lds_all);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
@@ -1306,7 +1497,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
     // the shading waves fill the issue slots in between (A/B on one device, here and in tail_stream: +1.4 %; the scan alone
     // raised: +0.9 %; the shading raised instead: -0.3 %; three levels, scan above the rest: +0.9 % — profiles/r03_tail_spill.txt)
     __builtin_amdgcn_s_setprio(1);
-    Hit h = path_scan_wave<LEAN>(sv, fp, s, alive, primary_mask, primary_mask2, scratch RT_PH_ARGS);
+    Hit h = path_scan_wave<LEAN, LISTS>(sv, fp, s, alive, primary_mask, primary_mask2, scratch RT_PH_ARGS);
     primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
     if (alive && h.obj < 0) {  // frag.hlsl:14-17: a miss ends the path (its skybox texel is fetched in path_end)
       (void)path_shade<RT_DEFER_SKY_BLOCKS, LEAN>(sv, fp, s, h, 0.0f, 0.0f, 0.0f);
@@ -1694,13 +1885,15 @@ __global__ void __launch_bounds__(NW * 64, WAVES) bounce_stream(DeviceScene sc, 
 #define RT_TAIL_WAVES 5  // waves per SIMD tail_stream is budgeted for (96 registers, no scratch; 6: 52 B, 7: 92 B of scratch per lane —
                          // A/B on one device at threshold 32: 53.0 / 51.8 / 49.3 Grays/s)
 #endif
-template <int NW, int WAVES>
+template <int NW, int WAVES, bool LISTS = false>
 __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, FrameParams fp, uint32_t refill_min, uint32_t chunk) {
   extern __shared__ float4 lds_all[];
-  for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
-  __syncthreads();
-  const SceneView sv = make_view(sc, lds_all, lds_all);
-  unsigned char *scratch = reinterpret_cast<unsigned char *>(lds_all + sc.image_records);  // NW x kScanScratchBytes
+  if (!LISTS) {
+    for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
+    __syncthreads();
+  }
+  const SceneView sv = LISTS ? make_view(sc, sc.image, sc.image) : make_view(sc, lds_all, lds_all);
+  unsigned char *scratch = reinterpret_cast<unsigned char *>(lds_all + (LISTS ? 0u : sc.image_records));  // NW x kScanScratchBytes (kListScratchBytes)
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   // Every wave draws on ONE shard of the queue, its own: the workgroups of render_blocks append to the shards in turn and
@@ -1808,7 +2001,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, Fr
     }
     RT_PH_MARK(3)
     __builtin_amdgcn_s_setprio(1);
-    h = path_scan_wave<true>(sv, fp, s, alive, nullptr, nullptr, scratch RT_PH_ARGS);
+    h = path_scan_wave<true, LISTS>(sv, fp, s, alive, nullptr, nullptr, scratch RT_PH_ARGS);
     if (alive && h.obj < 0) {  // frag.hlsl:14-17: a miss ends the path (its skybox texel is fetched in path_end)
       (void)path_shade<RT_DEFER_SKY_BLOCKS, true>(sv, fp, s, h, 0.0f, 0.0f, 0.0f);
       alive = false;
@@ -2025,6 +2218,66 @@ __global__ void __launch_bounds__(256) dirmask_build_kernel(DirMaskParams dm, co
   if (dm.words > 1u) table[e * dm.words + 1u] = w[1];
 }
 
+// Fills the candidate-list table of a large scene (rt_dirmask.h "Candidate lists"): one workgroup per cell.  It first collects,
+// in slot order, the spheres near enough to be listed by ANY entry of the cell (lower distance bound within the largest reach) —
+// a few dozen of a thousand — and every thread then builds the entries of its bins from those alone.  A cell with more near
+// spheres than the LDS list holds is counted in *overflow and left without entries (reach 0: its rays scan linearly); the host
+// then rebuilds with a shorter reach.  The block after the last cell writes the all-zero entry lanes without a lookup read.
+constexpr uint32_t kDirListNearCap = 1024;
+__global__ void __launch_bounds__(256) dirlist_build_kernel(DirMaskParams dm, const float4 *reg, uint32_t n, uint4 *table, uint32_t n_cells,
+                                                            uint32_t *overflow) {
+  __shared__ float4 near_rec[kDirListNearCap];
+  __shared__ uint16_t near_slot[kDirListNearCap];
+  __shared__ uint32_t wave_count[4];
+  const uint32_t cell = blockIdx.x;
+  if (cell >= n_cells) {
+    if (threadIdx.x < 2u) table[2u * static_cast<size_t>(dm.entries) + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const DirListGeom g0 = dirlist_geometry(dm, cell, 0u);  // centre and extents are the cell's, whatever the bin
+  const float reach_max = dm.reach_unit * static_cast<float>(kDirListReachQuanta);
+  uint32_t count = 0;  // the same in every thread
+  for (uint32_t base = 0; base < n; base += 256u) {
+    const uint32_t i = base + threadIdx.x;
+    bool near = false;
+    float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (i < n) {
+      r = reg[i];
+      // dirlist_candidate's own distance bound: a sphere it can list has dmin <= reach_max (or touches the cell, or is NaN)
+      const float vx = r.x - g0.p.x, vy = r.y - g0.p.y, vz = r.z - g0.p.z;
+      const float l2 = vx * vx + vy * vy + vz * vz;
+      const float R = r.w + g0.h;
+      near = !(l2 > R * R * 1.0001f) || !(fmaxf(sqrtf(l2) * 0.9999f - R, 0.0f) > reach_max);
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(near);
+    if (lane == 0) wave_count[wave] = static_cast<uint32_t>(__popcll(m));
+    __syncthreads();
+    uint32_t before = count, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; ++w) {
+      before += w < wave ? wave_count[w] : 0u;
+      total += wave_count[w];
+    }
+    const uint32_t pos = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+    if (near && pos < kDirListNearCap) {
+      near_rec[pos] = r;
+      near_slot[pos] = static_cast<uint16_t>(i);
+    }
+    count += total;
+    __syncthreads();
+  }
+  const bool too_many = count > kDirListNearCap;
+  if (too_many && threadIdx.x == 0) atomicAdd(overflow, 1u);
+  for (uint32_t bin = threadIdx.x; bin < dm.bins; bin += 256u) {
+    uint32_t w[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (!too_many) dirlist_entry(dm, cell, bin, near_rec, near_slot, count, w);
+    uint4 *e = table + 2u * (static_cast<size_t>(cell) * dm.bins + bin);
+    e[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    e[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+
 // Second pass of a batch launch (rt_render_frames): folds the batch's float samples into the history
 // in frame order, i.e. replays frag.hlsl:60-65 + the Rgba8UnormSrgb store once per frame exactly as
 // path_end would have done in `batch` separate launches (same expression, same quantisation of every
@@ -2189,7 +2442,8 @@ int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfi
     // (tools/variant_sweep.py, ms per frame tiles / re-packing: 1080p N = 2: 0.0737 / 0.0667, N = 4: 0.0420 / 0.0400, N = 8:
     // 0.0312 / 0.0309; 4K N = 8: 0.0683 / 0.0640)
     const uint64_t enough = fp.batch > 1u ? 20000ull : (sc.dm.enabled ? 4000ull : 24000ull);
-    variant = (sc.n_sph_pad > 136u || tiles < enough || sc.grid.enabled) ? 0 : 3;  // up to 128 spheres (+ 8 padding records)
+    // up to 128 spheres (+ 8 padding records), or a large scene with candidate lists
+    variant = (((sc.n_sph_pad > 136u || sc.grid.enabled) && !sc.dm.lists) || tiles < enough) ? 0 : 3;
 #if RT_STREAM_MIN_TILES
     if (variant == 3 && tiles >= RT_STREAM_MIN_TILES && sample_only(fp)) variant = 4;
 #endif
@@ -2200,10 +2454,13 @@ int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfi
   // bounce count and 26 bits of pixel index; the default re-packing shape carries both in full
   if ((variant == 4 || (variant == 3 && !RT_PACK_HITS)) && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26)))
     variant = variant == 4 && RT_PACK_HITS ? 3 : 0;
-  // the re-packing, streamed and resident-wave shapes keep the whole scene image in LDS; bigger scenes render as tiles
-  if ((variant == 3 || variant == 2 || variant == 4) && !image_fits) variant = 0;
+  // the streamed and resident-wave shapes have no candidate-list form
+  if ((variant == 2 || variant == 4) && sc.dm.lists) variant = 3;
+  // the re-packing, streamed and resident-wave shapes keep the whole scene image in LDS; bigger scenes render as tiles (the re-packing
+  // shape of a scene with candidate lists stages nothing)
+  if ((variant == 3 || variant == 2 || variant == 4) && !image_fits && !sc.dm.lists) variant = 0;
   // tiles whose sphere records do not fit a workgroup's default 64 KB of LDS scan them from global memory
-  if (variant == 0 && !image_fits && lds_sph > 60u * 1024u) variant = 1;
+  if (variant == 0 && !image_fits && lds_sph > 60u * 1024u && !sc.dm.lists) variant = 1;
   return variant;
 }
 
@@ -2240,54 +2497,61 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
                        fp, static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 3) {
     const dim3 blocks((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW, tiles_y, fp.batch);  // x: tile columns, y: tile rows, z: frames
-    const size_t bytes = lds_image + kBlocksLdsExtra;  // exchange buffer and the waves' scan scratch
+    const bool lists = sc.dm.enabled && sc.dm.lists;
+    // the staged scene image + exchange buffer and the waves' scan scratch; with candidate lists nothing is staged
+    const size_t bytes = lists ? kBlocksLdsExtraLists : lds_image + kBlocksLdsExtra;
+    const size_t tail_bytes = lists ? RT_TAIL_NW * kListScratchBytes : lds_image + RT_TAIL_NW * kScanScratchBytes;
     const bool lean = sample_only(fp);
+    const bool spill = lean && fp.spill_max != 0u && fp.queue != nullptr;
+    const dim3 threads(RT_BLOCK_NW * 64);
+#define RT_LAUNCH_BLOCKS(WAVES, LEAN_, SPILL_)                                                                                            \
+  do {                                                                                                                                    \
+    if (lists) hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, WAVES, LEAN_, SPILL_, true>), blocks, threads, bytes, stream, sc, fp);       \
+    else hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, WAVES, LEAN_, SPILL_, false>), blocks, threads, bytes, stream, sc, fp);           \
+  } while (0)
     if (fp.batch > 1u && lean) {
-      const bool spill = fp.spill_max != 0u && fp.queue != nullptr;
-      if (sc.dm.enabled && sc.dm.words > 1u) {
+      if (lists) {
+        if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_LISTS;
+        if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_LISTS, true, true);
+        else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_LISTS, true, false);
+      } else if (sc.dm.enabled && sc.dm.words > 1u) {
         if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH_WIDE;
-        if (spill)
-          hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH_WIDE, true, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
-        else
-          hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH_WIDE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+        if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH_WIDE, true, true);
+        else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH_WIDE, true, false);
       } else {
         if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
-        if (spill)
-          hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
-        else
-          hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_BATCH, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
-      }
-      if (spill) {  // the spilled paths' remaining bounces, in full waves
-        if (stage_used) *stage_used += 100;
-        if (lc.tail_start != nullptr) (void)hipEventRecord(lc.tail_start, stream);
-        const uint32_t blocks2 = static_cast<uint32_t>(lc.tail_blocks < 1 ? 1 : lc.tail_blocks);
-        const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
-        hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES>), dim3(blocks2), dim3(RT_TAIL_NW * 64),
-                           lds_image + RT_TAIL_NW * kScanScratchBytes, stream, sc, fp, static_cast<uint32_t>(lc.refill_min), chunk);
+        if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH, true, true);
+        else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH, true, false);
       }
     } else if (lean) {
-      const bool spill = fp.spill_max != 0u && fp.queue != nullptr;
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
-      if (spill) {
-        if (stage_used) *stage_used += 100;
-        hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
-        if (lc.tail_start != nullptr) (void)hipEventRecord(lc.tail_start, stream);
-        const uint32_t blocks2 = static_cast<uint32_t>(lc.tail_blocks < 1 ? 1 : lc.tail_blocks);
-        const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
-        hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES>), dim3(blocks2), dim3(RT_TAIL_NW * 64),
-                           lds_image + RT_TAIL_NW * kScanScratchBytes, stream, sc, fp, static_cast<uint32_t>(lc.refill_min), chunk);
-      } else {
-        hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_SINGLE, true>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
-      }
+      if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_SINGLE, true, true);
+      else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_SINGLE, true, false);
     } else {
       if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_FULL;
-      hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, RT_BLOCKS_WAVES_FULL, false>), blocks, dim3(RT_BLOCK_NW * 64), bytes, stream, sc, fp);
+      RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_FULL, false, false);
+    }
+#undef RT_LAUNCH_BLOCKS
+    if (spill) {  // the spilled paths' remaining bounces, in full waves
+      if (stage_used) *stage_used += 100;
+      if (lc.tail_start != nullptr) (void)hipEventRecord(lc.tail_start, stream);
+      const uint32_t blocks2 = static_cast<uint32_t>(lc.tail_blocks < 1 ? 1 : lc.tail_blocks);
+      const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
+      if (lists)
+        hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES, true>), dim3(blocks2), dim3(RT_TAIL_NW * 64), tail_bytes, stream, sc, fp,
+                           static_cast<uint32_t>(lc.refill_min), chunk);
+      else
+        hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES, false>), dim3(blocks2), dim3(RT_TAIL_NW * 64), tail_bytes, stream, sc, fp,
+                           static_cast<uint32_t>(lc.refill_min), chunk);
     }
   } else {
     const dim3 blocks((tiles_x + (kTileBlock / 64) - 1) / (kTileBlock / 64), tiles_y, fp.batch);
-    if (stage_used) *stage_used = variant == 1 ? 0 : ((sc.grid.enabled && !(lc.flags & 2)) ? 3 : (image_fits ? 2 : 1));
+    const bool lists = sc.dm.enabled && sc.dm.lists;
+    if (stage_used) *stage_used = variant == 1 ? 0 : (lists ? 4 : ((sc.grid.enabled && !(lc.flags & 2)) ? 3 : (image_fits ? 2 : 1)));
     if (variant == 1) {
       hipLaunchKernelGGL(render_tiles<0>, blocks, dim3(kTileBlock), 0, stream, sc, fp);
+    } else if (lists) {
+      hipLaunchKernelGGL(render_tiles<4>, blocks, dim3(kTileBlock), (kTileBlock / 64) * kListScratchBytes, stream, sc, fp);
     } else if (sc.grid.enabled && !(lc.flags & 2)) {  // RT_OPT_FLAGS bit 1: ignore the grid (A/B)
       const size_t bytes = lds_sph + (static_cast<size_t>(sc.grid.off_items - sc.grid.off_cells) +
                                       (static_cast<size_t>(sc.grid.n_items) * 2 + 15) / 16) * sizeof(float4);
@@ -2335,6 +2599,15 @@ int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n,
   return static_cast<int>(hipGetLastError());
 }
 
+int launch_dirlist_build(const DirMaskParams &dm, const float4 *reg, uint32_t n, unsigned long long *table, uint32_t *d_overflow,
+                         hipStream_t stream) {
+  const unsigned long long cells = static_cast<unsigned long long>(dm.nx) * dm.ny * dm.nz;
+  if (cells == 0 || cells > 0x7fffffffull || n == 0 || n > kDirListMaxSpheres || !dm.lists) return static_cast<int>(hipErrorInvalidValue);
+  hipLaunchKernelGGL(dirlist_build_kernel, dim3(static_cast<uint32_t>(cells) + 1u), dim3(256), 0, stream, dm, reg, n,
+                     reinterpret_cast<uint4 *>(table), static_cast<uint32_t>(cells), d_overflow);
+  return static_cast<int>(hipGetLastError());
+}
+
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap) {
   if (shard_cap) *shard_cap = 0;
   // sample-only launches of the re-packing shape whose secondary rays use the balanced scan (tail_stream has its scratch)
@@ -2353,12 +2626,13 @@ uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const Lau
   return static_cast<uint32_t>(t);
 }
 
-int tail_blocks_per_cu(size_t lds_bytes) {
+int tail_blocks_per_cu(size_t lds_bytes, bool lists) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_stream<RT_TAIL_NW, RT_TAIL_WAVES>, RT_TAIL_NW * 64,
-                                                   lds_bytes + RT_TAIL_NW * kScanScratchBytes) != hipSuccess)
-    return 0;
-  return n;
+  const hipError_t e = lists ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_stream<RT_TAIL_NW, RT_TAIL_WAVES, true>, RT_TAIL_NW * 64,
+                                                                            RT_TAIL_NW * kListScratchBytes)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_stream<RT_TAIL_NW, RT_TAIL_WAVES, false>, RT_TAIL_NW * 64,
+                                                                            lds_bytes + RT_TAIL_NW * kScanScratchBytes);
+  return e == hipSuccess ? n : 0;
 }
 
 int stream_blocks_per_cu(size_t lds_bytes) {

@@ -91,6 +91,7 @@ struct rt_context {
   int tail_spill_single = kDefaultTailSpillSingle;  // RT_OPT_TAIL_SPILL_SINGLE: the same for single-frame launches in flight
   int tail_occupancy_blocks = 0;       // resident tail_stream workgroups per CU for tail_occupancy_records of scene image
   uint32_t tail_occupancy_records = 0;
+  bool tail_occupancy_lists = false;
   int flags = 0;            // RT_OPT_FLAGS
   int cull = 1;             // RT_OPT_CULL: 0 off, 1 on, 2 on + self-check against the full scan
   unsigned long long *d_masks = nullptr;  // per-tile sphere masks of the primary-ray culling
@@ -144,6 +145,15 @@ struct rt_context {
   size_t dirmask_cap = 0;        // in 64-bit words
   float4 *d_dirmask_reg = nullptr;
   std::vector<float4> dirmask_built_for;  // sphere records (+ one record of options) the table on the device was built from
+  // candidate lists (rt_dirmask.h "Candidate lists"): scenes of more than 128 spheres
+  int dirlist_on = 1;                               // RT_OPT_DIRLIST
+  int dirlist_min_spheres = static_cast<int>(kDirMaskMaxSpheres) + 1;  // RT_OPT_DIRLIST_MIN
+  int dirlist_cells = kDefaultDirlistCells;         // RT_OPT_DIRLIST_CELLS
+  int dirlist_k = kDefaultDirlistK;                 // RT_OPT_DIRLIST_K
+  int dirlist_reach = kDefaultDirlistReach;         // RT_OPT_DIRLIST_REACH
+  size_t dirmask_reg_cap = 0;                       // float4 records d_dirmask_reg holds
+  uint32_t *d_dirlist_overflow = nullptr;
+  uint32_t dirlist_reach_used = 0;                  // the reach (cells) the current table was built with
   int grid_min_spheres = kDefaultGridMinSpheres;  // RT_OPT_GRID_MIN: scenes with at least this many spheres get the uniform grid; up to 128 spheres the
                                // direction-mask table serves (A/B on one device, tools/dirmask_sweep.sh, Grays/s table / grid / linear:
                                // 80 spheres 60.0 / 47.3 / 45.7, 96: 53.8 / 45.3 / 40.3, 128: 40.6 / 40.3 / 30.6 before the re-packing
@@ -368,12 +378,89 @@ int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
       }
       ctx->dirmask_cap = need_words;
     }
-    if (!ctx->d_dirmask_reg) RT_HIP(ctx, hipMalloc(&ctx->d_dirmask_reg, kDirMaskMaxSpheres * sizeof(float4)));
+    if (ctx->dirmask_reg_cap < kDirMaskMaxSpheres) {
+      (void)hipFree(ctx->d_dirmask_reg);
+      ctx->d_dirmask_reg = nullptr;
+      ctx->dirmask_reg_cap = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_dirmask_reg, kDirMaskMaxSpheres * sizeof(float4)));
+      ctx->dirmask_reg_cap = kDirMaskMaxSpheres;
+    }
     RT_HIP(ctx, hipMemcpy(ctx->d_dirmask_reg, reg, n * sizeof(float4), hipMemcpyHostToDevice));
     if (launch_dirmask_build(dm, ctx->d_dirmask_reg, n, ctx->d_dirmask, ctx->stream) != 0)
       return fail(ctx, RT_ERR_DEVICE, "direction-mask build launch failed");
     ctx->dirmask_built_for = key;
     ctx->prep_pending_dirmask = true;
+  }
+  dm.table = ctx->d_dirmask;
+  ctx->scene.dm = dm;
+  return RT_OK;
+}
+
+// The candidate-list table of a large scene (rt_dirmask.h "Candidate lists"), built on the device and kept while the sphere
+// records and the table's options stay the same.  Leaves ctx->scene.dm disabled when the scene is not served (no memory for the
+// table: the caller then builds the sphere grid).  The caller has synchronised the context's stream.
+constexpr size_t kDirListMaxBytes = 768ull << 20;
+int build_dirlist(rt_context *ctx, const float4 *sph, uint32_t n) {
+  std::vector<float4> reg(n);
+  uint32_t target = static_cast<uint32_t>(ctx->dirlist_cells);
+  uint32_t reach = static_cast<uint32_t>(ctx->dirlist_reach);
+  const uint32_t k = static_cast<uint32_t>(ctx->dirlist_k);
+  auto bytes_of = [](const DirMaskParams &d) { return (static_cast<size_t>(d.nx) * d.ny * d.nz * d.bins + 1u) * 32u; };
+  DirMaskParams dm = dirlist_plan(sph, n, target, k, reach, reg.data());
+  while (dm.enabled && bytes_of(dm) > kDirListMaxBytes && target > 1u) {
+    target /= 2u;
+    dm = dirlist_plan(sph, n, target, k, reach, reg.data());
+  }
+  if (!dm.enabled || bytes_of(dm) > kDirListMaxBytes) return RT_OK;
+  for (;;) {
+    std::vector<float4> key(sph, sph + n);
+    key.push_back(make_float4(static_cast<float>(dm.nx), static_cast<float>(dm.ny), static_cast<float>(dm.nz), static_cast<float>(dm.k)));
+    key.push_back(make_float4(dm.cell[0], dm.bmin[0], dm.bmin[1], dm.bmin[2]));
+    key.push_back(make_float4(dm.reach_unit, dm.s_cap, -1.0f, static_cast<float>(ctx->dirlist_reach)));  // (-1: never equal to a mask table's key)
+    const bool same = ctx->d_dirmask && key.size() == ctx->dirmask_built_for.size() &&
+                      std::memcmp(key.data(), ctx->dirmask_built_for.data(), key.size() * sizeof(float4)) == 0;
+    if (same) {  // (the reach it ended up with is part of the kept state)
+      dm = dirlist_plan(sph, n, target, k, ctx->dirlist_reach_used, reg.data());
+      break;
+    }
+    ctx->dirmask_built_for.clear();
+    const size_t need_words = bytes_of(dm) / sizeof(unsigned long long);
+    if (ctx->dirmask_cap < need_words) {
+      (void)hipFree(ctx->d_dirmask);
+      ctx->d_dirmask = nullptr;
+      ctx->dirmask_cap = 0;
+      if (hipMalloc(&ctx->d_dirmask, need_words * sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipGetLastError();  // no room for the table: the scene renders without one (the sphere grid), it does not fail
+        ctx->d_dirmask = nullptr;
+        return RT_OK;
+      }
+      ctx->dirmask_cap = need_words;
+    }
+    if (ctx->dirmask_reg_cap < n) {
+      (void)hipFree(ctx->d_dirmask_reg);
+      ctx->d_dirmask_reg = nullptr;
+      ctx->dirmask_reg_cap = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_dirmask_reg, static_cast<size_t>(n) * sizeof(float4)));
+      ctx->dirmask_reg_cap = n;
+    }
+    if (!ctx->d_dirlist_overflow) RT_HIP(ctx, hipMalloc(&ctx->d_dirlist_overflow, sizeof(uint32_t)));
+    uint32_t reach_now = reach;
+    for (;;) {  // a cell whose near spheres overflow the builder's list asks for a shorter reach
+      RT_HIP(ctx, hipMemcpy(ctx->d_dirmask_reg, reg.data(), static_cast<size_t>(n) * sizeof(float4), hipMemcpyHostToDevice));
+      RT_HIP(ctx, hipMemsetAsync(ctx->d_dirlist_overflow, 0, sizeof(uint32_t), ctx->stream));
+      if (launch_dirlist_build(dm, ctx->d_dirmask_reg, n, ctx->d_dirmask, ctx->d_dirlist_overflow, ctx->stream) != 0)
+        return fail(ctx, RT_ERR_DEVICE, "candidate-list build launch failed");
+      uint32_t overflow = 0;
+      RT_HIP(ctx, hipMemcpyAsync(&overflow, ctx->d_dirlist_overflow, sizeof overflow, hipMemcpyDeviceToHost, ctx->stream));
+      RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (overflow == 0u || reach_now <= 1u) break;
+      reach_now = reach_now / 2u;
+      dm = dirlist_plan(sph, n, target, k, reach_now, reg.data());
+    }
+    ctx->dirlist_reach_used = reach_now;
+    ctx->dirmask_built_for = key;
+    ctx->prep_pending_dirmask = true;
+    break;
   }
   dm.table = ctx->d_dirmask;
   ctx->scene.dm = dm;
@@ -460,6 +547,7 @@ int rt_destroy(rt_context *ctx) {
   (void)hipFree(ctx->d_masks);
   (void)hipFree(ctx->d_dirmask);
   (void)hipFree(ctx->d_dirmask_reg);
+  (void)hipFree(ctx->d_dirlist_overflow);
   (void)hipFree(ctx->d_samples);
   (void)hipFree(ctx->d_queue[rt_context::kMaxInflight]);
   (void)hipFree(ctx->d_kept);
@@ -651,8 +739,16 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   sph_obj.resize(n_sph, -1);
   const size_t sph_obj_rec = (n_sph + 3) / 4;  // ints packed into float4 records
   const size_t image_records = 3 * n_sph + 4 * n_pl + sph_obj_rec;
-  // large scenes: uniform grid over the spheres, appended behind the image proper
-  GridBuild grid = build_grid(sph, n_sph_live, n_sph, static_cast<uint32_t>(ctx->grid_min_spheres));
+  // large scenes: candidate lists (built on the device, below); where those are off or cannot be built, a uniform grid over the
+  // spheres, appended behind the image proper
+  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old scene and its tables
+  ctx->scene.dm = DirMaskParams{};
+  if (ctx->dirmask_on && ctx->dirlist_on && n_sph_live >= static_cast<size_t>(ctx->dirlist_min_spheres) && n_sph_live <= kDirListMaxSpheres) {
+    const int drc = build_dirlist(ctx, sph.data(), static_cast<uint32_t>(n_sph_live));
+    if (drc != RT_OK) return drc;
+  }
+  const bool have_lists = ctx->scene.dm.enabled != 0u;
+  GridBuild grid = have_lists ? GridBuild{} : build_grid(sph, n_sph_live, n_sph, static_cast<uint32_t>(ctx->grid_min_spheres));
   const size_t cells_rec = grid.params.enabled ? (grid.cell_start.size() * 4 + 15) / 16 : 0;
   const size_t items_rec = grid.params.enabled ? (grid.items.size() * 2 + 15) / 16 : 0;
   const size_t total = image_records + cells_rec + items_rec;
@@ -675,7 +771,6 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
     put(grid.params.off_items, grid.items.data(), grid.items.size() * 2);
   }
 
-  RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still read the old scene
   if (ctx->scene_cap < total) {
     (void)hipFree(ctx->d_scene);
     ctx->d_scene = nullptr;
@@ -691,8 +786,7 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   ctx->scene.n_obj = object_count;
   ctx->scene.image_records = static_cast<uint32_t>(image_records);
   ctx->scene.grid = grid.params;
-  ctx->scene.dm = DirMaskParams{};
-  if (ctx->dirmask_on && !grid.params.enabled && n_sph_live >= static_cast<size_t>(ctx->dirmask_min_spheres) &&
+  if (!have_lists && ctx->dirmask_on && !grid.params.enabled && n_sph_live >= static_cast<size_t>(ctx->dirmask_min_spheres) &&
       n_sph_live <= kDirMaskMaxSpheres) {
     const int drc = build_dirmask(ctx, sph.data(), static_cast<uint32_t>(n_sph_live));
     if (drc != RT_OK) return drc;
@@ -856,6 +950,175 @@ int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, c
   const size_t entry = static_cast<size_t>(cell) * dm.bins + dirmask_bin(d, inv_major, dm.k, dm.half_k);
   mask2[0] = table[entry * dm.words];
   if (dm.words > 1u) mask2[1] = table[entry * dm.words + 1u];
+  return RT_OK;
+}
+
+// Host-side twin of the candidate lists (rt_dirmask.h "Candidate lists"), for testing them without a GPU: the plan, single
+// entries on demand (a whole table is hundreds of megabytes), and a lane's walk through its rounds.
+static DirMaskParams dirlist_from_info(const rt_dirlist_info *info) {
+  DirMaskParams dm{};
+  dm.enabled = info->enabled;
+  dm.nx = info->nx;
+  dm.ny = info->ny;
+  dm.nz = info->nz;
+  dm.k = info->k;
+  dm.bins = info->bins;
+  dm.words = kDirListWords;
+  dm.entries = info->nx * info->ny * info->nz * info->bins;
+  dm.half_k = 0.5f * static_cast<float>(info->k);
+  dm.lists = 1;
+  dm.reach_unit = info->reach_unit;
+  dm.s_cap = info->s_cap;
+  for (int a = 0; a < 3; ++a) {
+    dm.bmin[a] = info->bmin[a];
+    dm.bmax[a] = info->bmax[a];
+    dm.cell[a] = info->cell[a];
+    dm.inv_cell[a] = info->inv_cell[a];
+  }
+  return dm;
+}
+
+int rt_dirlist_plan_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t target_cells, uint32_t k, uint32_t reach_cells,
+                         rt_dirlist_info *info, float *registered_xyzr) {
+  if (!info || (!spheres_xyzr2 && n_spheres)) return RT_ERR_INVALID_ARGUMENT;
+  std::memset(info, 0, sizeof *info);
+  try {
+    std::vector<float4> sph(n_spheres), reg(n_spheres);
+    for (uint32_t i = 0; i < n_spheres; ++i)
+      sph[i] = make_float4(spheres_xyzr2[4 * i], spheres_xyzr2[4 * i + 1], spheres_xyzr2[4 * i + 2], spheres_xyzr2[4 * i + 3]);
+    const DirMaskParams dm = dirlist_plan(sph.data(), n_spheres, target_cells, k, reach_cells, reg.data());
+    if (!dm.enabled) return RT_OK;
+    info->enabled = 1;
+    info->nx = dm.nx;
+    info->ny = dm.ny;
+    info->nz = dm.nz;
+    info->k = dm.k;
+    info->bins = dm.bins;
+    info->reach_unit = dm.reach_unit;
+    info->s_cap = dm.s_cap;
+    for (int a = 0; a < 3; ++a) {
+      info->bmin[a] = dm.bmin[a];
+      info->bmax[a] = dm.bmax[a];
+      info->cell[a] = dm.cell[a];
+      info->inv_cell[a] = dm.inv_cell[a];
+    }
+    if (registered_xyzr) std::memcpy(registered_xyzr, reg.data(), static_cast<size_t>(n_spheres) * sizeof(float4));
+    return RT_OK;
+  } catch (...) {
+    return RT_ERR_OUT_OF_MEMORY;
+  }
+}
+
+int rt_dirlist_entry_host(const rt_dirlist_info *info, const float *registered_xyzr, uint32_t n_spheres, uint32_t cell, uint32_t bin,
+                          uint32_t *entry8) {
+  if (!info || !info->enabled || !registered_xyzr || !entry8 || cell >= info->nx * info->ny * info->nz || bin >= info->bins)
+    return RT_ERR_INVALID_ARGUMENT;
+  const DirMaskParams dm = dirlist_from_info(info);
+  dirlist_entry(dm, cell, bin, reinterpret_cast<const float4 *>(registered_xyzr), nullptr, n_spheres, entry8);
+  return RT_OK;
+}
+
+// One ray through the rounds of intersect_listed (rt_kernels.hip), with IEEE reciprocals where the device uses v_rcp_f32 and
+// entries computed on demand: *listed_key / *listed_slot = what the rounds find (slot -1: nothing; *far = 1: the ray is not
+// served and the kernel scans linearly — then they are the linear result), *linear_key / *linear_slot = the linear scan of
+// all spheres with the same arithmetic; `t_plane`: the distance of the ray's plane hit (a large value for none), which ends the
+// rounds like a sphere hit does.  The two results must be equal for every ray.
+int rt_dirlist_walk_host(const rt_dirlist_info *info, const float *spheres_xyzr2, const float *registered_xyzr, uint32_t n_spheres,
+                         const float *origin3, const float *direction3, float t_plane, uint32_t *listed_key, int32_t *listed_slot,
+                         uint32_t *linear_key, int32_t *linear_slot, uint32_t *rounds, uint32_t *tests, int *far) {
+  if (!info || !info->enabled || !spheres_xyzr2 || !registered_xyzr || !origin3 || !direction3 || !listed_key || !listed_slot ||
+      !linear_key || !linear_slot || !rounds || !tests || !far)
+    return RT_ERR_INVALID_ARGUMENT;
+  constexpr uint32_t kEps = 0x358637bdu, kNone = 0x49742400u - kEps;  // as in rt_kernels.hip
+  const DirMaskParams dm = dirlist_from_info(info);
+  const f3 o = mk3(origin3[0], origin3[1], origin3[2]), d = mk3(direction3[0], direction3[1], direction3[2]);
+  auto test = [&](uint32_t i, uint32_t &key, int32_t &slot) {  // one sphere of ray.hlsl:53-68, the kernels' arithmetic
+    const float *g = spheres_xyzr2 + 4 * static_cast<size_t>(i);
+    const float nx = o.x - g[0], ny = o.y - g[1], nz = o.z - g[2];
+    const float dn = fmaf(d.z, nz, fmaf(d.y, ny, d.x * nx));
+    const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g[3]));
+    if (fminf(q, -dn) >= 0.0f) {
+      const uint32_t k = f2u(-dn - sqrtf(q)) - kEps;
+      if (k < key || (k == key && k < kNone && static_cast<int32_t>(i) < slot)) {
+        if (k < kNone) {
+          key = k;
+          slot = static_cast<int32_t>(i);
+        }
+      }
+    }
+  };
+  *linear_key = kNone;
+  *linear_slot = -1;
+  for (uint32_t i = 0; i < n_spheres; ++i) test(i, *linear_key, *linear_slot);
+  *listed_key = kNone;
+  *listed_slot = -1;
+  *rounds = 0;
+  *tests = 0;
+  *far = 0;
+  const bool unit = fabsf(dot3(d, d) - 1.0f) <= 4e-6f;
+  const bool inside = (o.x >= dm.bmin[0]) && (o.x <= dm.bmax[0]) && (o.y >= dm.bmin[1]) && (o.y <= dm.bmax[1]) && (o.z >= dm.bmin[2]) &&
+                      (o.z <= dm.bmax[2]);
+  bool todo = unit, is_far = !unit;
+  float s = 0.0f;
+  if (todo && !inside) {
+    const float big = 1e30f;
+    const float ivx = fabsf(d.x) > 1e-30f ? 1.0f / d.x : (d.x < 0.0f ? -big : big);
+    const float ivy = fabsf(d.y) > 1e-30f ? 1.0f / d.y : (d.y < 0.0f ? -big : big);
+    const float ivz = fabsf(d.z) > 1e-30f ? 1.0f / d.z : (d.z < 0.0f ? -big : big);
+    const float ax = (dm.bmin[0] - o.x) * ivx, bx = (dm.bmax[0] - o.x) * ivx;
+    const float ay = (dm.bmin[1] - o.y) * ivy, by = (dm.bmax[1] - o.y) * ivy;
+    const float az = (dm.bmin[2] - o.z) * ivz, bz = (dm.bmax[2] - o.z) * ivz;
+    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const bool finite = (o.x == o.x) && (o.y == o.y) && (o.z == o.z);
+    const bool misses = finite && !(t_in <= t_out);
+    const bool beyond = !finite || (t_in > dm.s_cap);
+    s = t_in;
+    is_far = beyond;
+    todo = !misses && !beyond;
+  }
+  const float inv_major = 1.0f / fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
+  const uint32_t bin = unit ? dirmask_bin(d, inv_major, dm.k, dm.half_k) : 0u;
+  while (todo) {
+    if (*rounds == 48u) {
+      is_far = true;
+      break;
+    }
+    *rounds += 1;
+    const f3 p = fma3(d, s, o);
+    uint32_t e[8];
+    dirlist_entry(dm, dirmask_cell(dm, p), bin, reinterpret_cast<const float4 *>(registered_xyzr), nullptr, n_spheres, e);
+    const uint32_t n = (e[0] >> 12) & 15u, q = e[0] & 0xfffu;
+    for (uint32_t j = 0; j < n; ++j) {
+      const uint32_t hw = 1u + j;
+      test((e[hw >> 1] >> (16u * (hw & 1u))) & 0xffffu, *listed_key, *listed_slot);
+      *tests += 1;
+    }
+    const float t_sphere = u2f(*listed_key + kEps);
+    const float t_near = fminf(t_plane, t_sphere);
+    const float reach = static_cast<float>(q) * dm.reach_unit;
+    if (q == 0u) {
+      is_far = true;
+      todo = false;
+    } else if (t_near <= fmaf(reach, kDirListDone, s)) {
+      todo = false;
+    } else {
+      s = fmaf(reach, kDirListStep, s);
+      const f3 pn = fma3(d, s, o);
+      const bool in_box = (pn.x >= dm.bmin[0]) && (pn.x <= dm.bmax[0]) && (pn.y >= dm.bmin[1]) && (pn.y <= dm.bmax[1]) &&
+                          (pn.z >= dm.bmin[2]) && (pn.z <= dm.bmax[2]);
+      if (!in_box) todo = false;
+      else if (s > dm.s_cap) {
+        is_far = true;
+        todo = false;
+      }
+    }
+  }
+  if (is_far) {
+    *far = 1;
+    *listed_key = *linear_key;
+    *listed_slot = *linear_slot;
+  }
   return RT_OK;
 }
 
@@ -1088,6 +1351,24 @@ int rt_set_option(rt_context *ctx, int option, int value) {
     case RT_OPT_DIRMASK_K:
       if (value < 1 || value > static_cast<int>(kDirMaskMaxK)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_DIRMASK_K takes 1..%u", kDirMaskMaxK);
       ctx->dirmask_k = value;
+      return RT_OK;
+    case RT_OPT_DIRLIST:
+      ctx->dirlist_on = value != 0;
+      return RT_OK;
+    case RT_OPT_DIRLIST_MIN:
+      ctx->dirlist_min_spheres = value < 1 ? 1 : value;
+      return RT_OK;
+    case RT_OPT_DIRLIST_CELLS:
+      if (value < 1 || value > 2097152) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_DIRLIST_CELLS takes 1..2097152");
+      ctx->dirlist_cells = value;
+      return RT_OK;
+    case RT_OPT_DIRLIST_K:
+      if (value < 1 || value > static_cast<int>(kDirMaskMaxK)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_DIRLIST_K takes 1..%u", kDirMaskMaxK);
+      ctx->dirlist_k = value;
+      return RT_OK;
+    case RT_OPT_DIRLIST_REACH:
+      if (value < 1 || value > 128) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_DIRLIST_REACH takes 1..128");
+      ctx->dirlist_reach = value;
       return RT_OK;
     case RT_OPT_TAIL_SPILL:
       if (value < 0 || value > 128) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TAIL_SPILL takes 0..128");
@@ -1427,9 +1708,11 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
         fp.queue_shard_cap = shard_cap;
         fp.queue_plane = plane;
         fp.spill_max = t;
-        if (ctx->tail_occupancy_records != ctx->scene.image_records || ctx->tail_occupancy_blocks == 0) {
-          ctx->tail_occupancy_blocks = tail_blocks_per_cu(static_cast<size_t>(ctx->scene.image_records) * sizeof(float4));
+        const bool lists_now = ctx->scene.dm.enabled && ctx->scene.dm.lists;
+        if (ctx->tail_occupancy_records != ctx->scene.image_records || ctx->tail_occupancy_blocks == 0 || ctx->tail_occupancy_lists != lists_now) {
+          ctx->tail_occupancy_blocks = tail_blocks_per_cu(static_cast<size_t>(ctx->scene.image_records) * sizeof(float4), lists_now);
           ctx->tail_occupancy_records = ctx->scene.image_records;
+          ctx->tail_occupancy_lists = lists_now;
         }
         const int per_cu_tail = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : (ctx->tail_occupancy_blocks > 0 ? ctx->tail_occupancy_blocks : 4);
         lc.tail_blocks = per_cu_tail * ctx->cu_count;
@@ -1479,6 +1762,7 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   ctx->stats.grid_items = ctx->scene.grid.enabled ? ctx->scene.grid.n_items : 0u;
   ctx->stats.dirmask_cells = ctx->scene.dm.enabled ? ctx->scene.dm.nx * ctx->scene.dm.ny * ctx->scene.dm.nz : 0u;
   ctx->stats.dirmask_bins = ctx->scene.dm.enabled ? ctx->scene.dm.bins : 0u;
+  ctx->stats.dirmask_lists = (ctx->scene.dm.enabled && ctx->scene.dm.lists) ? ctx->dirlist_reach_used : 0u;
   if (fp.hits) {
     ctx->hits_valid = true;
     ctx->hits_rendered_limit = fp.reflection_limit;

@@ -1,0 +1,180 @@
+"""The candidate lists of large scenes (rsraytracingv3_amd/csrc/rt_dirmask.h, "Candidate lists") on the CPU tier.
+
+A secondary ray of a scene with more than 128 spheres tests only the spheres its table entries list, in rounds, and stops
+when its best hit lies inside the reach of the entry it has just tested.  Checked here with the host twin of a lane's walk
+(``rt_dirlist_walk_host``: the plan and entry functions the device builder runs, the lane's round logic with IEEE
+reciprocals) against the linear scan of every sphere in the same arithmetic: the (key, slot) result must be EQUAL for every
+ray — the oracle's own secondary rays of the 1 024-sphere scene, rays along the ground, rays from outside the spheres' box,
+random rays — and the lists must be short, which is the point.  (The GPU tier repeats this inside the kernels with
+RT_OPT_CULL = 2 and compares whole frames with the oracle.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+import oracle
+from rsraytracingv3_amd import _native as N
+from rsraytracingv3_amd.scene import Camera
+
+
+def sphere_records(scene):
+    out, slots = [], {}
+    for i, o in enumerate(scene.objects):
+        if o.geometry.kind == 0:
+            slots[i] = len(out)
+            out.append((*o.geometry.center, np.float32(o.geometry.radius) * np.float32(o.geometry.radius)))
+    return np.array(out, np.float32), slots
+
+
+class Lists:
+    def __init__(self, spheres, cells=4096, k=6, reach=8):
+        self.lib = N.load()
+        self.sph = np.ascontiguousarray(spheres, np.float32)
+        self.n = len(self.sph)
+        self.info = N.RtDirListInfo()
+        self.reg = np.zeros((max(self.n, 1), 4), np.float32)
+        rc = self.lib.rt_dirlist_plan_host(self.sph.ctypes.data_as(C.c_void_p), self.n, cells, k, reach, C.byref(self.info),
+                                           self.reg.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+
+    def entry(self, cell, bin_):
+        e = np.zeros(8, np.uint32)
+        assert self.lib.rt_dirlist_entry_host(C.byref(self.info), self.reg.ctypes.data_as(C.c_void_p), self.n, cell, bin_,
+                                              e.ctypes.data_as(C.c_void_p)) == 0
+        h = e.view(np.uint16)
+        n, q = int(h[0]) >> 12, int(h[0]) & 0xfff
+        return n, q, [int(x) for x in h[1:1 + n]]
+
+    def walk(self, o, d, t_plane=1e30):
+        o = np.ascontiguousarray(o, np.float32)
+        d = np.ascontiguousarray(d, np.float32)
+        lk, ls, fk, fs = C.c_uint32(), C.c_int32(), C.c_uint32(), C.c_int32()
+        rounds, tests, far = C.c_uint32(), C.c_uint32(), C.c_int()
+        rc = self.lib.rt_dirlist_walk_host(C.byref(self.info), self.sph.ctypes.data_as(C.c_void_p), self.reg.ctypes.data_as(C.c_void_p),
+                                           self.n, o.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), t_plane, C.byref(lk),
+                                           C.byref(ls), C.byref(fk), C.byref(fs), C.byref(rounds), C.byref(tests), C.byref(far))
+        assert rc == 0
+        return (lk.value, ls.value), (fk.value, fs.value), rounds.value, tests.value, bool(far.value)
+
+
+def check_oracle_rays(scene, size, lists, every=1, jitter=(0.1, -0.2)):
+    w, h = size
+    sky, rnd = cases.inputs(64, 32)
+    frame, rays = oracle.render_with_rays(scene.live_object_bytes(), len(scene.objects), scene.config_bytes(w, h), jitter, 0, sky, rnd,
+                                          threads=4)
+    _, slots = sphere_records(scene)
+    checked = far_n = tests = rounds = 0
+    count = 0
+    for y in range(h):
+        for x in range(w):
+            for i in range(1, int(frame.segments[y, x])):  # secondary iterations only: primary rays use the tile masks
+                count += 1
+                if count % every:
+                    continue
+                o, d = rays[y, x, i, :3], rays[y, x, i, 3:]
+                listed, linear, r, t, far = lists.walk(o, d)
+                assert listed == linear, "pixel (%d, %d) iteration %d: lists %r, linear scan %r" % (x, y, i, listed, linear)
+                obj = int(frame.hits[y, x, i])
+                if obj in slots:  # and the linear scan here is the oracle's
+                    assert linear[1] == slots[obj]
+                checked += 1
+                far_n += far
+                if not far:
+                    tests += t
+                    rounds += r
+    return checked, far_n, tests / max(checked - far_n, 1), rounds / max(checked - far_n, 1)
+
+
+def test_walk_equals_linear_scan_on_the_oracles_rays_1024_spheres():
+    scene = cases.stress_scene(1024, 8)
+    sph, _ = sphere_records(scene)
+    lists = Lists(sph, cells=16384, k=8, reach=16)
+    assert lists.info.enabled and lists.info.nx > 64  # finer than the 64 cells per axis of the bit-set table
+    checked, far, mean_tests, mean_rounds = check_oracle_rays(scene, (96, 54), lists, every=3)
+    assert checked > 2000 and far < 0.02 * checked
+    assert mean_tests < 12.0 and mean_rounds < 2.0, (mean_tests, mean_rounds)  # of 1 024 spheres
+
+
+def test_walk_equals_linear_scan_on_other_views_and_scenes():
+    # along the ground from inside the disc: long shallow rays through many entries
+    scene = cases.stress_scene(1024, 6)
+    sph, _ = sphere_records(scene)
+    lists = Lists(sph, cells=4096, k=6, reach=6)
+    scene.camera = Camera((70.0, 2.5, 10.0), (0.02, -1.6, 0.0), 80.0)
+    check_oracle_rays(scene, (64, 36), lists, every=2)
+    # from far above
+    scene.camera = Camera((5.0, 600.0, 5.0), (1.5, 0.0, 0.0), 40.0)
+    check_oracle_rays(scene, (48, 27), lists, every=2)
+    # a medium scene of larger spheres, short reaches
+    medium = cases.spheres_scene(200, 8, seed=7, min_r=2.0, max_r=6.0, placement=80.0, request=320)
+    msph, _ = sphere_records(medium)
+    check_oracle_rays(medium, (64, 36), Lists(msph, cells=2048, k=4, reach=3))
+
+
+def test_random_rays_inside_outside_and_degenerate():
+    rng = np.random.default_rng(5)
+    scene = cases.stress_scene(300, 8)
+    sph, _ = sphere_records(scene)
+    lists = Lists(sph, cells=2048, k=6, reach=8)
+    info = lists.info
+    lo, hi = np.array(info.bmin[:]), np.array(info.bmax[:])
+    n_far = 0
+    for trial in range(1500):
+        kind = trial % 5
+        if kind == 0:    # inside the box
+            o = lo + rng.random(3) * (hi - lo)
+        elif kind == 1:  # around the box
+            o = lo - 0.5 * (hi - lo) + rng.random(3) * 2.0 * (hi - lo)
+        elif kind == 2:  # on a sphere's surface, as a bounce leaves it
+            c = sph[rng.integers(len(sph))]
+            v = rng.normal(size=3)
+            o = c[:3] + v / np.linalg.norm(v) * (np.sqrt(c[3]) + 1e-3)
+        elif kind == 3:  # far away
+            o = (rng.random(3) - 0.5) * 5000.0
+        else:            # on the ground
+            o = np.array([lo[0] + rng.random() * (hi[0] - lo[0]), 0.001, lo[2] + rng.random() * (hi[2] - lo[2])])
+        d = rng.normal(size=3)
+        if trial % 7 == 0:
+            d[1] *= 0.02   # nearly horizontal: across the whole disc
+        d = d / np.linalg.norm(d)
+        if trial % 97 == 0:
+            d = d * 1.01   # not a unit vector: not served
+        listed, linear, rounds, tests, far = lists.walk(o.astype(np.float32), d.astype(np.float32))
+        assert listed == linear, (trial, o, d, listed, linear)
+        n_far += far
+        if trial % 97 == 0:
+            assert far
+    assert n_far < 600
+    nan = lists.walk([np.nan, 0.0, 0.0], [0.0, -1.0, 0.0])
+    assert nan[4] and nan[0] == nan[1] and nan[0][1] == -1
+
+
+def test_entries_are_short_sorted_and_flag_what_they_cannot_serve():
+    scene = cases.stress_scene(1024, 8)
+    sph, _ = sphere_records(scene)
+    lists = Lists(sph, cells=16384, k=8, reach=16)
+    info = lists.info
+    rng = np.random.default_rng(1)
+    cells = info.nx * info.ny * info.nz
+    for _ in range(300):
+        n, q, slots = lists.entry(int(rng.integers(cells)), int(rng.integers(info.bins)))
+        assert n <= 15 and q > 0 and slots == sorted(slots) and all(s < 1024 for s in slots)
+    # forty spheres on one spot: more than 15 registered balls overlap every nearby cell -> those entries have no reach
+    heap = np.tile(np.array([[0.0, 1.0, 0.0, 1.0]], np.float32), (40, 1))
+    heap[:, 0] += np.arange(40, dtype=np.float32) * 1e-3
+    spread = np.concatenate([heap, sph[:200]])
+    crowded = Lists(spread, cells=512, k=4, reach=4)
+    ci = crowded.info
+    cell = [int((0.0 - ci.bmin[a]) * ci.inv_cell[a]) for a in range(3)]
+    cell[1] = int((1.0 - ci.bmin[1]) * ci.inv_cell[1])
+    n, q, slots = crowded.entry((cell[2] * ci.ny + cell[1]) * ci.nx + cell[0], 0)
+    assert q == 0 and n == 0
+    listed, linear, rounds, tests, far = crowded.walk([0.0, 1.0, 0.0], [1.0, 0.0, 0.0])
+    assert far and listed == linear
+
+
+def test_scenes_that_are_not_served():
+    assert not Lists(np.zeros((0, 4), np.float32)).info.enabled
+    bad = np.array([[0, 0, 0, 1], [np.inf, 0, 0, 1]], np.float32)
+    assert not Lists(bad).info.enabled

@@ -805,3 +805,95 @@ def test_direction_mask_table_is_kept_while_the_spheres_stay(device):
         outs, st = run_gpu(device, scene, size, sky, rnd, (0.1, 0.1), max_objects="live")
         assert st.dirmask_cells > 0
         assert_frame_equal(outs[0], run_oracle(scene, size, sky, rnd, (0.1, 0.1), max_objects="live"))
+
+
+@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("case", ["stress_1024", "stress_300", "stress_129", "inside_the_scene", "heap"])
+def test_candidate_lists_never_change_a_frame(device, variant, case):
+    """rt_dirmask.h "Candidate lists": secondary rays of scenes with more than 128 spheres test only the spheres their table
+    entries list, in rounds (a ray whose best hit lies beyond its entry's reach looks the next entry up further along).  The
+    frame must be the oracle's (= the linear scan's) bit for bit at several table resolutions and reaches, RT_OPT_CULL = 2
+    re-scans every ray linearly inside the kernel and counts disagreements (zero), and the sphere grid (lists off) gives the
+    same frame."""
+    from rsraytracingv3_amd.scene import Camera, Geometry, Material, Object
+    size, jitter = (200, 112), (0.3, -0.2)
+    if case == "stress_1024":
+        scene = cases.stress_scene(1024, 8)
+    elif case == "stress_300":
+        scene = cases.stress_scene(300, 6)
+        scene.camera = Camera((60.0, 40.0, 60.0), (0.5, -0.8, 0.0), 70.0)
+    elif case == "stress_129":
+        scene = cases.stress_scene(129, 6)
+        scene.camera = Camera((60.0, 40.0, 60.0), (0.5, -0.8, 0.0), 70.0)
+    elif case == "inside_the_scene":  # camera between the spheres, looking along the ground: long shallow rays through many entries
+        scene = cases.stress_scene(1024, 8)
+        scene.camera = Camera((70.0, 2.5, 10.0), (0.02, -1.6, 0.0), 80.0)
+    else:  # forty overlapping spheres on one spot: entries without a reach, their rays scan linearly
+        scene = cases.stress_scene(200, 6)
+        heap = [Object("Heap %d" % i, Material((0.9, 0.5, 0.2), (0.0, 0.0, 0.0), 0.0, 0.5, 0.3 if i % 2 else 0.0),
+                       Geometry.sphere((10.0 + 0.01 * i, 4.0, -5.0), 4.0)) for i in range(40)]
+        scene.objects = heap + scene.objects
+        scene.camera = Camera((40.0, 30.0, 30.0), (0.6, -0.9, 0.0), 70.0)
+    sky, rnd = cases.inputs(64, 32)
+    ref = run_oracle(scene, size, sky, rnd, jitter, max_objects="live")
+    try:
+        for k, cells, reach in ((8, 16384, 16), (3, 64, 2), (12, 2048, 64), (6, 100000, 5)):
+            device.set_option(N.RT_OPT_DIRLIST, 1)
+            device.set_option(N.RT_OPT_DIRLIST_K, k)
+            device.set_option(N.RT_OPT_DIRLIST_CELLS, cells)
+            device.set_option(N.RT_OPT_DIRLIST_REACH, reach)
+            device.set_option(N.RT_OPT_CULL, 2)
+            outs, st = run_gpu(device, scene, size, sky, rnd, jitter, max_objects="live", variant=variant)
+            assert st.dirmask_cells > 0 and st.dirmask_bins == 6 * k * k and st.dirmask_lists > 0 and st.grid_cells == 0, "the scene got no lists"
+            assert st.last_variant == variant and (variant == 3 or st.last_stage == 4)
+            assert st.last_cull_mismatches == 0
+            assert_frame_equal(outs[0], ref)
+        device.set_option(N.RT_OPT_DIRLIST, 0)
+        outs, st = run_gpu(device, scene, size, sky, rnd, jitter, max_objects="live", variant=variant)
+        assert st.dirmask_lists == 0 and st.grid_cells > 0
+        assert_frame_equal(outs[0], ref)
+    finally:
+        device.set_option(N.RT_OPT_DIRLIST, 1)
+        device.set_option(N.RT_OPT_DIRLIST_K, 8)
+        device.set_option(N.RT_OPT_DIRLIST_CELLS, 16384)
+        device.set_option(N.RT_OPT_DIRLIST_REACH, 16)
+        device.set_option(N.RT_OPT_CULL, 1)
+
+
+@pytest.mark.parametrize("spheres", [1024, 260])
+def test_candidate_lists_in_multi_frame_launches_with_a_tail_spill(device, spheres):
+    """The headline launch shape on a large scene: render_blocks<.., LISTS> re-packs, hands its last paths to tail_stream<.., LISTS>,
+    nothing is staged into LDS.  Texels, floats and totals of a six-frame launch equal the sequential frames' at several spill
+    thresholds, and the sequential frames are the oracle's chain."""
+    scene = cases.stress_scene(spheres, 8)
+    size = (333, 187)
+    sky, rnd = cases.inputs(64, 32)
+    jit = [(0.1, -0.2), (-0.33, 0.27), (0.45, 0.05), (-0.49, -0.49), (0.0, 0.31), (0.2, 0.2)]
+    try:
+        device.set_option(N.RT_OPT_FLAGS, 4)  # launches of every size spill
+        device.set_option(N.RT_OPT_TAIL_SPILL, 0)
+        (seq, bat0), st0 = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_SRGB8, 3, (0, 1, 8), "live")
+        assert st0.last_variant == 3 and st0.last_stage < 100 and st0.dirmask_lists > 0
+        assert np.array_equal(seq[0], bat0[0]) and np.array_equal(seq[1].view(np.uint32), bat0[1].view(np.uint32))
+        hist = None
+        for k in range(len(jit)):
+            ref = run_oracle(scene, size, sky, rnd, jit[k], max_objects="live", pc=k, history=hist)
+            hist = ref.rgba8
+        assert np.array_equal(seq[0], hist), "the sequential frames are not the oracle's chain"
+        for t, refill_min, chunk in ((4, 1, 1), (32, 16, 2), (128, 64, 1)):
+            device.set_option(N.RT_OPT_TAIL_SPILL, t)
+            device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, t)
+            device.set_option(N.RT_OPT_REFILL_MIN, refill_min)
+            device.set_option(N.RT_OPT_TILE_CHUNK, chunk)
+            (seq_t, bat), st = _batch_vs_sequential(device, scene, size, sky, rnd, jit, 0, N.RT_ACCUM_SRGB8, 3, (0, 1, 8), "live")
+            assert st.last_variant == 3 and st.last_stage >= 100, "the launch did not take the spilling shape"
+            assert (st.last_segments, st.last_rough_hits) == (st0.last_segments, st0.last_rough_hits)
+            assert np.array_equal(seq[0], bat[0]), "threshold %d: texels differ" % t
+            assert np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32)), "threshold %d: floats differ" % t
+            assert np.array_equal(seq[0], seq_t[0])
+    finally:
+        device.set_option(N.RT_OPT_FLAGS, 0)
+        device.set_option(N.RT_OPT_TAIL_SPILL, N.RT_TAIL_SPILL_DEFAULT)
+        device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, 0)
+        device.set_option(N.RT_OPT_REFILL_MIN, 1)
+        device.set_option(N.RT_OPT_TILE_CHUNK, 2)
