@@ -18,6 +18,7 @@ RT_OUT_RGBA8, RT_OUT_RGBF32, RT_OUT_SEGMENTS, RT_OUT_HITS = 1, 2, 4, 8
 RT_OPT_VARIANT, RT_OPT_REFILL_MIN, RT_OPT_BLOCKS_PER_CU, RT_OPT_TILE_CHUNK, RT_OPT_FLAGS, RT_OPT_CULL = 0, 1, 2, 3, 4, 5
 RT_OPT_INFLIGHT, RT_OPT_GRID_MIN, RT_OPT_BATCH_INFLIGHT = 6, 7, 8
 RT_OPT_DIRMASK, RT_OPT_DIRMASK_MIN, RT_OPT_DIRMASK_CELLS, RT_OPT_DIRMASK_K, RT_OPT_TAIL_SPILL = 9, 10, 11, 12, 13
+RT355_PRESENT_SLOTS = 4
 RT_TAIL_SPILL_DEFAULT = 32  # kDefaultTailSpill (csrc/rt_device.h)
 RT_OPT_TAIL_SPILL_SINGLE = 14  # default 0
 RT_OPT_DIRLIST, RT_OPT_DIRLIST_MIN, RT_OPT_DIRLIST_CELLS, RT_OPT_DIRLIST_K, RT_OPT_DIRLIST_REACH = 15, 16, 17, 18, 19
@@ -135,6 +136,10 @@ SIGNATURES = {
     "rt_read_rgbf32_rows": (_i, [_vp, _u32, _u32, _vp, _sz]),
     "rt_read_segments": (_i, [_vp, _vp, _sz]),
     "rt_read_hits": (_i, [_vp, _vp, _sz]),
+    "rt_present_async": (_i, [_vp, _u32]),
+    "rt_present_wait": (_i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_u32), C.POINTER(_u32)]),
+    "rt_multi_present_async": (_i, [_vp, _u32]),
+    "rt_multi_present_wait": (_i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_u32), C.POINTER(_u32)]),
     "rt_write_history_rgba8": (_i, [_vp, _vp, _sz]),
     "rt_get_device_buffers": (_i, [_vp, C.POINTER(RtDeviceBuffers)]),
     "rt_get_stats": (_i, [_vp, C.POINTER(RtStats)]),

@@ -250,6 +250,20 @@ class RenderTarget:
     def _local_rows(self) -> int:
         return self.device.stats().local_rows
 
+    def present_async(self, slot: int = 0):
+        """render_target.rs:50-70 without stalling the render loop: queue the copy of the frames launched so far into pinned
+        staging buffer ``slot``; it runs beside the next frames' rendering (``rt_present_async``)."""
+        self.device.call("rt_present_async", slot)
+
+    def present_wait(self, slot: int = 0, copy: bool = True) -> np.ndarray:
+        """The texels queued by ``present_async(slot)`` (blocks until they have arrived).  ``copy=False`` returns a view of the
+        pinned buffer, valid until the slot's next ``present_async``."""
+        ptr, size, rows, width = C.c_void_p(), C.c_size_t(), C.c_uint32(), C.c_uint32()
+        self.device.call("rt_present_wait", slot, C.byref(ptr), C.byref(size), C.byref(rows), C.byref(width))
+        buf = (C.c_uint8 * size.value).from_address(ptr.value)
+        view = np.frombuffer(buf, np.uint8).reshape(rows.value, width.value, 4)
+        return view.copy() if copy else view
+
     def read_rgba8(self, rows: Optional[Tuple[int, int]] = None) -> np.ndarray:
         """The stored texels; ``rows`` = (first, count) reads that band of local rows only."""
         if rows is not None:

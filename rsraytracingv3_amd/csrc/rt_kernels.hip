@@ -60,6 +60,15 @@ namespace {
 #ifndef RT_BLOCKS_WAVES_LISTS
 #define RT_BLOCKS_WAVES_LISTS 6   // ... for large scenes (candidate lists; nothing staged into LDS)
 #endif
+#ifndef RT_LIST_TRIPS2
+#define RT_LIST_TRIPS2 1  // candidate-list scan: two (ray, sphere) pairs per lane and trip, their dependent reads in flight together
+#endif
+#ifndef RT_LIST_EARLY_X
+#define RT_LIST_EARLY_X 1  // kernels of large scenes: the shading's random() texels requested around the scan
+#endif
+#ifndef RT_LAZY_OBJ
+#define RT_LAZY_OBJ 1     // sample-only kernels of large scenes: a sphere hit's object index is fetched only to break a distance tie with a plane
+#endif
 #ifndef RT_BLOCKS_WAVES_SINGLE
 #define RT_BLOCKS_WAVES_SINGLE 5  // ... in sample-only single-frame launches, several of which are in flight (register count held at the
                                   // 5-wave step).  5 / 6 / 7 waves, one frame per launch at 8 bounces: 47.2 / 44.8 / 46.3 Grays/s before the
@@ -168,12 +177,21 @@ __device__ __forceinline__ float rcp_of_root(float s) {
 // render_blocks, summed into words 4.. of the launch's counter shard.  Compiles to nothing otherwise.
 #ifdef RT_PROFILE_PHASES
 #define RT_PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define RT_PH_MARK(k)                                                \
+#define RT_PH_MARK_RAW(k)                                            \
   {                                                                  \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime();    \
     ph_acc[k] += now_ - ph_t;                                        \
     ph_t = now_;                                                     \
   }
+#ifdef RT_PH_LISTS  // (diagnostic build of the candidate-list scan's own stamps: slots 0..6 are its steps, 7 everything else)
+#define RT_PH_MARK(k) RT_PH_MARK_RAW(7)
+#define RT_PHL(k) RT_PH_MARK_RAW(k)
+#define RT_PHL_WAIT __builtin_amdgcn_s_waitcnt(0);
+#else
+#define RT_PH_MARK(k) RT_PH_MARK_RAW(k)
+#define RT_PHL(k)
+#define RT_PHL_WAIT
+#endif
 #define RT_PH_FLUSH(shard)                                                                         \
   if ((threadIdx.x & 63u) == 0)                                                                    \
     for (int k_ = 0; k_ < 8; ++k_)                                                                 \
@@ -183,6 +201,8 @@ __device__ __forceinline__ float rcp_of_root(float s) {
 #else
 #define RT_PH_DECL
 #define RT_PH_MARK(k)
+#define RT_PHL(k)
+#define RT_PHL_WAIT
 #define RT_PH_FLUSH(shard)
 #define RT_PH_PARAMS
 #define RT_PH_ARGS
@@ -486,6 +506,87 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
   return SphereHit{best_key, slot};
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave (DPP row shifts, then the two cross-row broadcasts of gfx9).
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x111, 0xf, 0xf, true));  // row_shr:1
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x112, 0xf, 0xf, true));  // row_shr:2
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x114, 0xf, 0xf, true));  // row_shr:4
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x118, 0xf, 0xf, true));  // row_shr:8
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x142, 0xa, 0xf, true));  // row_bcast:15 -> rows 1, 3
+  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xc, 0xf, true));  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+// The same scan for the kernels of large scenes (nothing staged: a sphere record is a memory round trip, and a thousand spheres are
+// 16 mask words): the wave reads its mask words side by side — lane l the word l — compacts the set bits into a candidate list
+// (ascending sphere index), fetches 64 candidates' records with ONE gather, and every ray then tests them from registers
+// (v_readlane broadcasts): two dependent memory round trips per tile instead of one per mask word and one per candidate.
+// Every lane of the wave must call it; `alive` = the lane carries a ray.  `scratch_base`: kListScratchBytes per wave.
+__device__ __forceinline__ SphereHit scan_spheres_listed_wide(const float4 *__restrict__ sph, f3 o, f3 d, bool alive,
+                                                              const unsigned long long *__restrict__ col_mask,
+                                                              const unsigned long long *__restrict__ row_mask, uint32_t words,
+                                                              unsigned char *scratch_base) {
+  uint32_t tid = threadIdx.x;
+  asm volatile("; thread index re-read per scan" : "+v"(tid));
+  const uint32_t lane = tid & 63u;
+  uint16_t *cand = reinterpret_cast<uint16_t *>(scratch_base + (tid >> 6) * kListScratchBytes + 64u * 64u);  // the pair list's space
+  uint32_t best_key = kNoHitKey;
+  int slot = -1;
+  for (uint32_t wbase = 0u; wbase < words; wbase += 64u) {
+    const uint32_t w = wbase + lane;
+    unsigned long long m = 0ull;
+    if (w < words) m = col_mask[w] & row_mask[w];
+    const uint32_t cnt = static_cast<uint32_t>(__popcll(m));
+    const uint32_t incl = wave_inclusive_sum(cnt);
+    const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
+    RT_CNT(3, total)
+    for (uint32_t c0 = 0u; c0 < total; c0 += 64u) {  // 64 candidates at a time, ascending sphere index
+      {
+        uint32_t pos = incl - cnt - c0;  // place of this lane's first candidate in the window (wraps below it)
+        unsigned long long mm = m;
+        while (mm != 0ull) {
+          const uint32_t bit = static_cast<uint32_t>(__builtin_ctzll(mm));
+          mm &= mm - 1ull;
+          if (pos < 64u) cand[pos] = static_cast<uint16_t>(w * 64u + bit);
+          pos += 1u;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t n_win = min(64u, total - c0);
+      uint32_t idx = 0u;
+      float4 g = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (lane < n_win) {
+        idx = cand[lane];
+        g = sph[idx];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the next window's writes stay behind these reads
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (uint32_t j = 0u; j < n_win; ++j) {
+        const float gx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.x), static_cast<int>(j)));
+        const float gy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.y), static_cast<int>(j)));
+        const float gz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.z), static_cast<int>(j)));
+        const float gw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.w), static_cast<int>(j)));
+        const int i = __builtin_amdgcn_readlane(static_cast<int>(idx), static_cast<int>(j));
+        if (alive) {
+          const float nx = o.x - gx, ny = o.y - gy, nz = o.z - gz;
+          const float dn = fmaf(d.z, nz, fmaf(d.y, ny, d.x * nx));
+          const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - gw));
+          const unsigned long long hit = __builtin_amdgcn_fcmpf(fminf(q, -dn), 0.0f, 3 /* OGE */);
+          if (hit != 0ull) {
+            const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;
+            slot = (key < best_key) ? i : slot;
+            best_key = min(best_key, key);
+          }
+        }
+      }
+    }
+  }
+  return SphereHit{best_key, slot};
+}
+
 // ---- direction masks (rt_dirmask.h): secondary rays of scenes with up to 64 spheres --------------------------------
 // The table entry of this lane's ray.  Lanes without a ray, and rays that miss the box of the registered balls, get the
 // index of the table's extra all-zero entry (the one past the last cell), so that every lane can load its set without a
@@ -587,17 +688,6 @@ __device__ __forceinline__ SphereHit scan_spheres_masked(const float4 *__restric
 #undef RT_MASK_WORD
 #undef RT_MASK_TEST
   return SphereHit{best_key, slot};
-}
-
-// Inclusive prefix sum over the 64 lanes of a wave (DPP row shifts, then the two cross-row broadcasts of gfx9).
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
-  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x111, 0xf, 0xf, true));  // row_shr:1
-  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x112, 0xf, 0xf, true));  // row_shr:2
-  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x114, 0xf, 0xf, true));  // row_shr:4
-  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x118, 0xf, 0xf, true));  // row_shr:8
-  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x142, 0xa, 0xf, true));  // row_bcast:15 -> rows 1, 3
-  x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xc, 0xf, true));  // row_bcast:31 -> rows 2, 3
-  return x;
 }
 
 // The same result as scan_spheres_masked for every lane, with the work dealt evenly: a lane's own walk costs the wave as
@@ -829,6 +919,28 @@ __device__ __forceinline__ Hit merge_sphere_hit(const SceneView &sv, Hit h, Sphe
   return h;
 }
 
+// The same for kernels that never report object indices (sample-only launches) on scenes whose index table is a memory round trip
+// away: the sphere's object index is only fetched when its distance EQUALS the plane hit's (the tie-break of ray.hlsl:97-107's
+// ascending order); otherwise any non-negative value says "hit".
+__device__ __forceinline__ Hit merge_sphere_hit_lazy(const SceneView &sv, Hit h, SphereHit sh) {
+  if (sh.slot >= 0) {
+    const float t = __uint_as_float(sh.key + kEpsBits);
+    int obj = 0;
+    bool wins = t < h.t;
+    if (t == h.t) {  // rare
+      obj = sv.sph_obj[sh.slot];
+      wins = (h.obj < 0) | (obj < h.obj);
+    }
+    if (wins) {
+      h.t = t;
+      h.obj = obj;
+      h.slot = sh.slot;
+      h.plane = false;
+    }
+  }
+  return h;
+}
+
 // ray_intersect (ray.hlsl:97-107) for the lanes of a wave whose rays the direction-mask table serves: the set is loaded
 // (every lane, no branch: lanes without a ray read the table's zero entry), the planes are tested while it is on its way,
 // then each lane tests its candidates.  One instance per entry width, so that the loaded registers go straight into the
@@ -877,7 +989,7 @@ __device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const Frame
 // `scratch_base`: kListScratchBytes per wave.
 template <bool LEAN>
 __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const FrameParams &fp, f3 o, f3 d, bool alive, Hit miss,
-                                                unsigned char *scratch_base) {
+                                                unsigned char *scratch_base RT_PH_PARAMS) {
   const DirMaskParams &dm = *sv.dm;
   uint32_t tid = threadIdx.x;
   asm volatile("; thread index re-read per scan" : "+v"(tid));
@@ -890,6 +1002,10 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
   const uint16_t *raw16 = reinterpret_cast<const uint16_t *>(raw);
   uint16_t *pairs = reinterpret_cast<uint16_t *>(scratch + 64u * 64u);
   RT_CNT(4, 1)
+#ifdef RT_PROFILE_EVENTS
+  const int n_rays_ = __popcll(__builtin_amdgcn_ballot_w64(alive));
+  RT_CNT(7, n_rays_)
+#endif
   const bool unit = fabsf(dot3(d, d) - 1.0f) <= 4e-6f;  // false for a NaN in d
   const bool inside = (o.x >= dm.bmin[0]) & (o.x <= dm.bmax[0]) & (o.y >= dm.bmin[1]) & (o.y <= dm.bmax[1]) & (o.z >= dm.bmin[2]) &
                       (o.z <= dm.bmax[2]);  // false for a NaN in o
@@ -924,6 +1040,7 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
   Hit hp = miss;
   bool planes_pending = true;
   const uint4 *table = reinterpret_cast<const uint4 *>(dm.table);
+  RT_PHL(0)
   for (uint32_t round = 0u; __builtin_amdgcn_ballot_w64(todo) != 0ull; ++round) {
     if (round == 48u) {  // rays that crawl through entries of tiny reaches (heaps of overlapping balls): the linear scan serves them
       far |= todo;
@@ -936,6 +1053,8 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
       if (alive) hp = nearest_plane(sv, o, d);
       planes_pending = false;
     }
+    RT_PHL_WAIT
+    RT_PHL(1)
     raw[2u * lane] = w0;
     raw[2u * lane + 1u] = w1;
     const uint32_t n = todo ? (w0.x >> 12) & 15u : 0u;
@@ -944,6 +1063,7 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     const uint32_t total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(incl), 63));
     RT_CNT(5, (total + 63u) >> 6)
     RT_CNT_LANE(6, n)
+    RT_CNT(2, 1)  // rounds
     {
       uint16_t *mine = pairs + (incl - n);
       const uint32_t tag = lane << 8;
@@ -954,6 +1074,39 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    RT_PHL(2)
+#if RT_LIST_TRIPS2
+    // two pairs per lane and trip: the two chains of dependent reads (pair -> slot -> sphere record, the last one from memory) are
+    // in flight together.  Lanes beyond the list read pair 0's operands (always there when total > 0) and drop the result.
+    for (uint32_t first = 0u; first < total; first += 128u) {  // wave-uniform trip count
+      const uint32_t ja = first + lane, jb = ja + 64u;
+      const bool va = ja < total, vb = jb < total;
+      const uint32_t pra = pairs[va ? ja : 0u], prb = pairs[vb ? jb : 0u];
+      const uint32_t owner_a = pra >> 8, owner_b = prb >> 8;
+      const uint32_t ia = raw16[owner_a * 16u + (pra & 255u)], ib = raw16[owner_b * 16u + (prb & 255u)];
+      const float4 raa = rays_a[owner_a], rab = rays_a[owner_b];
+      const float2 rba = rays_b[owner_a], rbb = rays_b[owner_b];
+      const float4 ga = sv.sph[ia], gb = sv.sph[ib];
+      {
+        const float nx = raa.x - ga.x, ny = raa.y - ga.y, nz = raa.z - ga.z;
+        const float dn = fmaf(rba.y, nz, fmaf(rba.x, ny, raa.w * nx));
+        const float qd = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - ga.w));
+        if (va && fminf(qd, -dn) >= 0.0f) {
+          const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(qd)) - kEpsBits;
+          if (key < kNoHitKey) atomicMin(&best[owner_a], (static_cast<unsigned long long>(key) << 32) | ia);
+        }
+      }
+      if (__builtin_amdgcn_ballot_w64(vb) != 0ull) {
+        const float nx = rab.x - gb.x, ny = rab.y - gb.y, nz = rab.z - gb.z;
+        const float dn = fmaf(rbb.y, nz, fmaf(rbb.x, ny, rab.w * nx));
+        const float qd = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - gb.w));
+        if (vb && fminf(qd, -dn) >= 0.0f) {
+          const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(qd)) - kEpsBits;
+          if (key < kNoHitKey) atomicMin(&best[owner_b], (static_cast<unsigned long long>(key) << 32) | ib);
+        }
+      }
+    }
+#else
     for (uint32_t first = 0u; first < total; first += 64u) {  // wave-uniform trip count
       const uint32_t j = first + lane;
       if (j < total) {
@@ -972,9 +1125,12 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
         }
       }
     }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    RT_PHL_WAIT
+    RT_PHL(3)
     if (todo) {
       const uint32_t key = static_cast<uint32_t>(best[lane] >> 32);
       const float t_sphere = __uint_as_float(key + kEpsBits);  // 1e6 when nothing has hit: beyond any reach that matters
@@ -998,6 +1154,7 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
       }
     }
   }
+  RT_PHL(4)
   if (planes_pending && alive) hp = nearest_plane(sv, o, d);  // no lane looked anything up
   SphereHit sh;
   {
@@ -1018,7 +1175,10 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
     if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
   }
-  return alive ? merge_sphere_hit(sv, hp, sh) : miss;
+  const Hit merged = alive ? ((LEAN && RT_LAZY_OBJ) ? merge_sphere_hit_lazy(sv, hp, sh) : merge_sphere_hit(sv, hp, sh)) : miss;
+  RT_PHL_WAIT
+  RT_PHL(5)
+  return merged;
 }
 
 // State of one pixel's path between two iterations of frag.hlsl:36-43.
@@ -1060,7 +1220,9 @@ __device__ __forceinline__ void path_begin(const FrameParams &fp, uint32_t x, ui
 // LEAN: the launch writes float samples only (multi-frame launches and the single-frame launches in flight: no
 // per-frame diagnostic outputs, no history, the sRGB store happens in resolve_batch_kernel) — the kernel is
 // compiled without those paths.
-template <bool DEFER_SKY, bool LEAN = false>
+// X2_GIVEN: x2 and seed1 are the second random() texel and the RNG state it was addressed with (requested by the caller, early);
+// otherwise the texel is requested here, when the hit turns out rough.
+template <bool DEFER_SKY, bool LEAN = false, bool X2_GIVEN = (RT_X2_PREFETCH != 0)>
 __device__ __forceinline__ bool path_shade(const SceneView &sv, const FrameParams &fp, Path &s, const Hit h,
                                            const float x1, const float x2, const float seed1) {
   if (!LEAN && fp.hits) fp.hits[static_cast<size_t>(s.p) * fp.reflection_limit + s.seg] = h.obj;
@@ -1091,15 +1253,13 @@ __device__ __forceinline__ bool path_shade(const SceneView &sv, const FrameParam
   const float k = 2.0f * dot3(nrm, s.d);          // reflect(), frag.hlsl:23
   f3 nd = fma3(nrm, -k, s.d);
   if (m0.w != 0.0f) {                             // random.hlsl:26-28
-#if RT_X2_PREFETCH
-    nd = hemisphere(s.rng, nd, m1.w, x1, x2, seed1);
-#else
-    {
+    if (X2_GIVEN) {
+      nd = hemisphere(s.rng, nd, m1.w, x1, x2, seed1);
+    } else {
       const float seed_a = rng_next_seed(s.rng.seed, x1);
       const float x2_now = fp.rnd[rng_texel(fp, Rng{seed_a, s.rng.px, s.rng.py})];
       nd = hemisphere(s.rng, nd, m1.w, x1, x2_now, seed_a);
     }
-#endif
     s.rough += 1;
   }
   s.d = nd;
@@ -1143,8 +1303,10 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
 #define RT_REQUEST_X2
 #endif
   if (primary_mask != nullptr) {  // wave-uniform: all live lanes carry primary rays of one tile
+    SphereHit sh{kNoHitKey, -1};
+    if (MODE == 2) sh = scan_spheres_listed_wide(sv.sph, s.o, s.d, alive, primary_mask, primary_mask2, fp.mask_words, scratch);
     if (alive) {
-      const SphereHit sh = scan_spheres_listed(sv.sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
+      if (MODE != 2) sh = scan_spheres_listed(sv.sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
       if (!LEAN && fp.cull_check) {  // self-check frame: the full scan must agree
         const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
         if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
@@ -1177,7 +1339,7 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
     miss.obj = -1;
     miss.slot = -1;
     miss.plane = false;
-    const Hit h = intersect_listed<LEAN>(sv, fp, s.o, s.d, alive, miss, scratch);
+    const Hit h = intersect_listed<LEAN>(sv, fp, s.o, s.d, alive, miss, scratch RT_PH_ARGS);
     RT_PH_MARK(1)
     RT_REQUEST_X2
     if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, h, x1, x2, seed1);
@@ -1237,8 +1399,10 @@ __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FramePa
   const uint32_t n_live = static_cast<uint32_t>(__popcll(live));
   if (n_live == 0u) return h;
   if (primary_mask != nullptr) {  // wave-uniform: all live lanes carry primary rays of one tile
+    SphereHit sh{kNoHitKey, -1};
+    if (LISTS) sh = scan_spheres_listed_wide(sv.sph, s.o, s.d, alive, primary_mask, primary_mask2, fp.mask_words, scratch);
     if (alive) {
-      const SphereHit sh = scan_spheres_listed(sv.sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
+      if (!LISTS) sh = scan_spheres_listed(sv.sph, s.o, s.d, primary_mask, primary_mask2, fp.mask_words);
       if (!LEAN && fp.cull_check) {  // self-check frame: the full scan must agree
         const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
         if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
@@ -1248,7 +1412,7 @@ __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FramePa
     RT_PH_MARK(0)
   } else if (LISTS) {
     // secondary rays of a large scene: candidate lists, in rounds (rt_dirmask.h)
-    h = intersect_listed<LEAN>(sv, fp, s.o, s.d, alive, h, scratch);
+    h = intersect_listed<LEAN>(sv, fp, s.o, s.d, alive, h, scratch RT_PH_ARGS);
     RT_PH_MARK(1)
   } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
     // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
@@ -1497,12 +1661,22 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
     // the shading waves fill the issue slots in between (A/B on one device, here and in tail_stream: +1.4 %; the scan alone
     // raised: +0.9 %; the shading raised instead: -0.3 %; three levels, scan above the rest: +0.9 % — profiles/r03_tail_spill.txt)
     __builtin_amdgcn_s_setprio(1);
+    // Large scenes (nothing staged: the kernel waits on memory, not on its issue slots): the two random() texels of the shading are
+    // requested around the scan — the first before it, the second (its address needs the first one's value) right after it —
+    // instead of one after the other at the head of the shading.  The RNG state does not change in between.
+    constexpr bool EARLY_X = LISTS && RT_LIST_EARLY_X;
+    float x1 = 0.0f, x2 = 0.0f, seed1 = 0.0f;
+    if (EARLY_X && alive) x1 = fp.rnd[rng_texel(fp, s.rng)];
     Hit h = path_scan_wave<LEAN, LISTS>(sv, fp, s, alive, primary_mask, primary_mask2, scratch RT_PH_ARGS);
     primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
     if (alive && h.obj < 0) {  // frag.hlsl:14-17: a miss ends the path (its skybox texel is fetched in path_end)
       (void)path_shade<RT_DEFER_SKY_BLOCKS, LEAN>(sv, fp, s, h, 0.0f, 0.0f, 0.0f);
       alive = false;
       finished = true;
+    }
+    if (EARLY_X && alive) {
+      seed1 = rng_next_seed(s.rng.seed, x1);
+      x2 = fp.rnd[rng_texel(fp, Rng{seed1, s.rng.px, s.rng.py})];
     }
     unsigned int *counts = wave_count[iters & 1u];
     iters += 1u;
@@ -1580,6 +1754,11 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
         h.slot = __float_as_int(g.y);
         h.obj = __float_as_int(g.z);
         h.plane = (__float_as_uint(g.w) & 1u) != 0u;
+        if (EARLY_X) {  // the lane carries another path now: its texels
+          x1 = fp.rnd[rng_texel(fp, s.rng)];
+          seed1 = rng_next_seed(s.rng.seed, x1);
+          x2 = fp.rnd[rng_texel(fp, Rng{seed1, s.rng.px, s.rng.py})];
+        }
       }
       live_waves = need;
       // No barrier here: the exchange buffer is next written after the next count barrier, which the
@@ -1588,8 +1767,8 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
     }
     __builtin_amdgcn_s_setprio(0);
     if (alive) {  // shade the hit; the first random() texel is requested here, by the lanes that still carry a path
-      const float x1 = fp.rnd[rng_texel(fp, s.rng)];
-      alive = path_shade<RT_DEFER_SKY_BLOCKS, LEAN>(sv, fp, s, h, x1, 0.0f, 0.0f);
+      if (!EARLY_X) x1 = fp.rnd[rng_texel(fp, s.rng)];
+      alive = path_shade<RT_DEFER_SKY_BLOCKS, LEAN, EARLY_X>(sv, fp, s, h, x1, x2, seed1);
       rough_total += s.rough & 0x7fffffffu;
       s.rough &= 0x80000000u;
       finished |= !alive;
@@ -1884,6 +2063,9 @@ __global__ void __launch_bounds__(NW * 64, WAVES) bounce_stream(DeviceScene sc, 
 #ifndef RT_TAIL_WAVES
 #define RT_TAIL_WAVES 5  // waves per SIMD tail_stream is budgeted for (96 registers, no scratch; 6: 52 B, 7: 92 B of scratch per lane —
                          // A/B on one device at threshold 32: 53.0 / 51.8 / 49.3 Grays/s)
+#endif
+#ifndef RT_TAIL_WAVES_LISTS
+#define RT_TAIL_WAVES_LISTS 4  // ... with candidate lists (128 registers, no scratch; at 5 it spills 32 B per lane: A/B on one device 34.5 / 34.35 Grays/s)
 #endif
 template <int NW, int WAVES, bool LISTS = false>
 __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, FrameParams fp, uint32_t refill_min, uint32_t chunk) {
@@ -2538,7 +2720,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
       const uint32_t blocks2 = static_cast<uint32_t>(lc.tail_blocks < 1 ? 1 : lc.tail_blocks);
       const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
       if (lists)
-        hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES, true>), dim3(blocks2), dim3(RT_TAIL_NW * 64), tail_bytes, stream, sc, fp,
+        hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES_LISTS, true>), dim3(blocks2), dim3(RT_TAIL_NW * 64), tail_bytes, stream, sc, fp,
                            static_cast<uint32_t>(lc.refill_min), chunk);
       else
         hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES, false>), dim3(blocks2), dim3(RT_TAIL_NW * 64), tail_bytes, stream, sc, fp,
@@ -2628,7 +2810,7 @@ uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const Lau
 
 int tail_blocks_per_cu(size_t lds_bytes, bool lists) {
   int n = 0;
-  const hipError_t e = lists ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_stream<RT_TAIL_NW, RT_TAIL_WAVES, true>, RT_TAIL_NW * 64,
+  const hipError_t e = lists ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_stream<RT_TAIL_NW, RT_TAIL_WAVES_LISTS, true>, RT_TAIL_NW * 64,
                                                                             RT_TAIL_NW * kListScratchBytes)
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, tail_stream<RT_TAIL_NW, RT_TAIL_WAVES, false>, RT_TAIL_NW * 64,
                                                                             lds_bytes + RT_TAIL_NW * kScanScratchBytes);

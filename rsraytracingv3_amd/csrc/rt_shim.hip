@@ -172,6 +172,20 @@ struct rt_context {
   int stream_occupancy_blocks = 0;
   uint32_t stream_occupancy_records = 0xffffffffu;
   uint64_t pipe_frames = 0;
+  // Asynchronous presentation (rt_present_async / rt_present_wait): pinned host staging buffers the frame's texels are copied
+  // into on a copy stream of their own, beside the next launches' rendering.
+  static constexpr uint32_t kPresentSlots = RT355_PRESENT_SLOTS;
+  hipStream_t present_stream = nullptr;
+  hipEvent_t present_ready = nullptr;                  // the frame to present is complete (recorded on the stream that produced it)
+  hipEvent_t present_done[kPresentSlots] = {};         // the copy into the slot has finished
+  void *present_host[kPresentSlots] = {};
+  size_t present_cap[kPresentSlots] = {};
+  size_t present_bytes[kPresentSlots] = {};
+  uint32_t present_rows[kPresentSlots] = {}, present_width[kPresentSlots] = {};
+  bool present_queued[kPresentSlots] = {};             // a copy into the slot has been queued (and not been waited for since)
+  uint32_t *d_present[kPresentSlots] = {};             // device-side snapshot of the frame the slot's copy reads: the target itself is
+  size_t present_dev_cap[kPresentSlots] = {};          // the history, which the next launch overwrites in place
+  int present_guard = -1;                              // (unused since the snapshots: kept -1)
   rt_stats stats{};
   std::string error;
 };
@@ -274,6 +288,8 @@ int alloc_target_buffers(rt_context *ctx, size_t px) {
 int alloc_target(rt_context *ctx) {
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->comm_stream) RT_HIP(ctx, hipStreamSynchronize(ctx->comm_stream));
+  if (ctx->present_stream) RT_HIP(ctx, hipStreamSynchronize(ctx->present_stream));  // a presentation copy may still read the old target
+  ctx->present_guard = -1;
   free_target(ctx);
   ctx->local_rows = count_local_rows(ctx->height, ctx->rank, ctx->world, ctx->strip_rows);
   ctx->masks_dirty = true;
@@ -558,6 +574,16 @@ int rt_destroy(rt_context *ctx) {
     if (ctx->render_stream[i]) (void)hipStreamDestroy(ctx->render_stream[i]);
   }
   if (ctx->prep_done) (void)hipEventDestroy(ctx->prep_done);
+  if (ctx->present_stream) {
+    (void)hipStreamSynchronize(ctx->present_stream);
+    (void)hipStreamDestroy(ctx->present_stream);
+  }
+  if (ctx->present_ready) (void)hipEventDestroy(ctx->present_ready);
+  for (uint32_t i = 0; i < rt_context::kPresentSlots; ++i) {
+    if (ctx->present_done[i]) (void)hipEventDestroy(ctx->present_done[i]);
+    if (ctx->present_host[i]) (void)hipHostFree(ctx->present_host[i]);
+    (void)hipFree(ctx->d_present[i]);
+  }
   (void)hipFree(ctx->d_lut);
   for (int i = 0; i < 2; ++i)
     if (ctx->rnd_last_use[i]) (void)hipEventDestroy(ctx->rnd_last_use[i]);
@@ -1721,6 +1747,10 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     }
   }
   ctx->tail_ran[slot] = fp.spill_max != 0u;
+  if (ctx->present_guard >= 0) {  // a presentation copy still reads the texels this launch (its resolve pass) overwrites
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->present_done[ctx->present_guard], 0));
+    ctx->present_guard = -1;
+  }
   RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], render_stream));
   int per_cu = ctx->blocks_per_cu;
   if (per_cu <= 0 && ctx->variant == 2) {  // only the resident-wave shape sizes its grid by occupancy
@@ -1842,6 +1872,82 @@ int rt_read_hits(rt_context *ctx, int32_t *dst, size_t bytes) {
     return fail(ctx, RT_ERR_NOT_READY, "rt_read_hits: the last frame was rendered with reflection_limit %u, the scene now "
                                        "has %u; render a frame first", ctx->hits_rendered_limit, ctx->config.reflection_limit);
   return read_back(ctx, ctx->d_hits, dst, bytes, 4 * static_cast<size_t>(ctx->hits_rendered_limit), "rt_read_hits");
+}
+
+// Asynchronous presentation.  `src` (device memory of `bytes` bytes) is complete once everything queued on `producer` so far has
+// run.  With snapshot = true the frame is first copied to a device buffer of the slot on the producer stream (a few
+// microseconds) and goes to the pinned host buffer from there, on `copier`: the producer's next launches overwrite `src` in
+// place (the target is the history) without waiting for the 0.16 ms the host copy of a 1080p frame takes, so consecutive
+// frames' host copies run back to back at the link's rate.  snapshot = false (copier == producer): ordered by the stream itself.
+static int present_from(rt_context *ctx, uint32_t slot, const void *src, size_t bytes, uint32_t rows, uint32_t width, hipStream_t producer,
+                        hipStream_t copier, bool snapshot) {
+  if (!ctx->present_done[slot]) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->present_done[slot], hipEventDisableTiming));
+  if (ctx->present_cap[slot] < bytes) {
+    if (ctx->present_queued[slot]) RT_HIP(ctx, hipEventSynchronize(ctx->present_done[slot]));
+    if (ctx->present_host[slot]) (void)hipHostFree(ctx->present_host[slot]);
+    ctx->present_host[slot] = nullptr;
+    ctx->present_cap[slot] = 0;
+    RT_HIP(ctx, hipHostMalloc(&ctx->present_host[slot], bytes, hipHostMallocDefault));
+    ctx->present_cap[slot] = bytes;
+  }
+  // the slot's previous copy (the caller has moved on to this frame: it no longer wants the old one) must not be overtaken
+  if (ctx->present_queued[slot]) RT_HIP(ctx, hipStreamWaitEvent(producer, ctx->present_done[slot], 0));
+  const void *from = src;
+  if (snapshot) {
+    if (ctx->present_dev_cap[slot] < bytes) {
+      if (ctx->present_queued[slot]) RT_HIP(ctx, hipEventSynchronize(ctx->present_done[slot]));
+      (void)hipFree(ctx->d_present[slot]);
+      ctx->d_present[slot] = nullptr;
+      ctx->present_dev_cap[slot] = 0;
+      RT_HIP(ctx, hipMalloc(&ctx->d_present[slot], bytes));
+      ctx->present_dev_cap[slot] = bytes;
+    }
+    RT_HIP(ctx, hipMemcpyAsync(ctx->d_present[slot], src, bytes, hipMemcpyDeviceToDevice, producer));
+    from = ctx->d_present[slot];
+  }
+  if (copier != producer) {
+    if (!ctx->present_ready) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->present_ready, hipEventDisableTiming));
+    RT_HIP(ctx, hipEventRecord(ctx->present_ready, producer));
+    RT_HIP(ctx, hipStreamWaitEvent(copier, ctx->present_ready, 0));
+  }
+  RT_HIP(ctx, hipMemcpyAsync(ctx->present_host[slot], from, bytes, hipMemcpyDeviceToHost, copier));
+  RT_HIP(ctx, hipEventRecord(ctx->present_done[slot], copier));
+  ctx->present_bytes[slot] = bytes;
+  ctx->present_rows[slot] = rows;
+  ctx->present_width[slot] = width;
+  ctx->present_queued[slot] = true;
+  return RT_OK;
+}
+
+int rt_present_async(rt_context *ctx, uint32_t slot) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (slot >= rt_context::kPresentSlots) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_present_async: slot %u of %u", slot, rt_context::kPresentSlots);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->comm) {  // a communicator's frame is assembled on rank 0, on the communication stream: the copy queues up behind the gather
+    if (ctx->comm_rank != 0) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_present_async: the frame is assembled on rank 0 only");
+    if (!ctx->d_frame) return fail(ctx, RT_ERR_NOT_READY, "rt_present_async: no target allocated");
+    return present_from(ctx, slot, ctx->d_frame, static_cast<size_t>(ctx->width) * ctx->height * 4, ctx->height, ctx->width, ctx->comm_stream,
+                        ctx->comm_stream, false);
+  }
+  const uint32_t *src = current_texels(ctx);
+  if (!src || !ctx->local_rows) return fail(ctx, RT_ERR_NOT_READY, "rt_present_async: no target allocated");
+  if (!ctx->present_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->present_stream, hipStreamNonBlocking));
+  return present_from(ctx, slot, src, static_cast<size_t>(ctx->local_rows) * ctx->width * 4, ctx->local_rows, ctx->width, ctx->stream,
+                      ctx->present_stream, true);
+}
+
+int rt_present_wait(rt_context *ctx, uint32_t slot, const void **texels, size_t *bytes, uint32_t *rows, uint32_t *width) {
+  if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  if (slot >= rt_context::kPresentSlots || !texels) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_present_wait: slot %u / NULL", slot);
+  if (!ctx->present_queued[slot]) return fail(ctx, RT_ERR_NOT_READY, "rt_present_wait: nothing was queued into slot %u (rt_present_async)", slot);
+  RT_HIP(ctx, hipSetDevice(ctx->device));
+  RT_HIP(ctx, hipEventSynchronize(ctx->present_done[slot]));
+  ctx->present_queued[slot] = false;
+  *texels = ctx->present_host[slot];
+  if (bytes) *bytes = ctx->present_bytes[slot];
+  if (rows) *rows = ctx->present_rows[slot];
+  if (width) *width = ctx->present_width[slot];
+  return RT_OK;
 }
 
 int rt_keep_batch_frames(rt_context *ctx, uint32_t every) {
@@ -2382,6 +2488,28 @@ int rt_multi_read_frame_rgba8(rt_multi *m, void *dst, size_t bytes) {
       hipStreamSynchronize(m->gather_stream) != hipSuccess)
     return multi_fail(m, RT_ERR_DEVICE, "rt_multi_read_frame_rgba8: copy failed");
   return RT_OK;
+}
+int rt_multi_present_async(rt_multi *m, uint32_t slot) {
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  rt_context *root = m->ctx[0];
+  if (m->ctx.size() == 1u) {
+    const int rc = rt_present_async(root, slot);
+    return rc == RT_OK ? RT_OK : multi_fail(m, rc, "rt_multi_present_async", root);
+  }
+  if (slot >= rt_context::kPresentSlots) return multi_fail(m, RT_ERR_INVALID_ARGUMENT, "rt_multi_present_async: no such slot");
+  if (!root->d_frame) return multi_fail(m, RT_ERR_NOT_READY, "rt_multi_present_async: no target (rt_multi_resize)");
+  if (hipSetDevice(m->device0) != hipSuccess) return multi_fail(m, RT_ERR_DEVICE, "rt_multi_present_async: hipSetDevice failed");
+  // behind the last gather on the gather stream: the next gather's assembly queues up behind the copy in turn
+  const int rc = present_from(root, slot, root->d_frame, static_cast<size_t>(root->width) * root->height * 4, root->height, root->width,
+                              m->gather_stream, m->gather_stream, false);
+  return rc == RT_OK ? RT_OK : multi_fail(m, rc, "rt_multi_present_async", root);
+}
+int rt_multi_present_wait(rt_multi *m, uint32_t slot, const void **texels, size_t *bytes, uint32_t *rows, uint32_t *width) {
+  if (!m) return RT_ERR_INVALID_ARGUMENT;
+  rt_context *root = m->ctx[0];
+  if (hipSetDevice(m->device0) != hipSuccess) return multi_fail(m, RT_ERR_DEVICE, "rt_multi_present_wait: hipSetDevice failed");
+  const int rc = rt_present_wait(root, slot, texels, bytes, rows, width);
+  return rc == RT_OK ? RT_OK : multi_fail(m, rc, "rt_multi_present_wait", root);
 }
 int rt_multi_get_stats(rt_multi *m, rt_stats *out) {
   if (!m || !out) return RT_ERR_INVALID_ARGUMENT;

@@ -9,7 +9,7 @@ import pytest
 
 import cases
 import oracle
-from rsraytracingv3_amd import Connection, MultiDevice, RandomTexture, RenderTarget, synth
+from rsraytracingv3_amd import Connection, Device, MultiDevice, RandomTexture, RenderTarget, synth
 from rsraytracingv3_amd import _native as N
 
 pytestmark = pytest.mark.gpu
@@ -192,3 +192,55 @@ def test_more_devices_than_strips():
         assert rows == [8, 8, 4, 0, 0, 0, 0, 0]
     finally:
         dev.close()
+
+
+@pytest.mark.parametrize("members", [1, 3])
+def test_asynchronous_presentation_equals_the_synchronous_read_back(members):
+    """rt_present_async / rt_present_wait (render_target.rs:50-70 every frame without stalling the loop): frame k's texels are
+    copied into a pinned staging slot on a copy stream while frame k + 1 renders; 12 accumulating frames arrive texel for
+    texel as a blocking read-back after every frame delivers them, the history (and with it every later frame) is untouched,
+    through one context and through an rt_multi's assembled frame."""
+    scene = cases.headline_scene(5)
+    size = (250, 141)
+    sky, rnd = cases.inputs(64, 32)
+    jit = synth.jitter_sequence(5, 12)
+
+    def run(asynchronous):
+        dev = MultiDevice([0] * members, 8) if members > 1 else Device(0)
+        try:
+            dev.set_outputs(N.RT_OUT_RGBA8)
+            target = RenderTarget.new(dev, size)
+            rt = RandomTexture(dev)
+            rt.write(rnd)
+            conn = Connection(scene, dev, sky, rt, max_objects="live")
+            conn.update_buffers(size, scene, (0.0, 0.0))
+            frames = []
+            for k in range(12):
+                conn.frame_data.jitter, conn.frame_data.progressive_count = (float(jit[k, 0]), float(jit[k, 1])), k
+                conn.draw()
+                if asynchronous:
+                    target.present_async(k % 2)          # queue frame k's copy ...
+                    if k:
+                        frames.append(target.present_wait((k - 1) % 2))  # ... and show frame k - 1 meanwhile
+                else:
+                    frames.append(dev.read_frame_rgba8(*size) if members > 1 else target.read_rgba8())
+            if asynchronous:
+                frames.append(target.present_wait(11 % 2))
+                with pytest.raises(N.RtError):
+                    target.present_wait(0)               # nothing queued into the slot since it was waited for
+                with pytest.raises(N.RtError):
+                    target.present_async(N.RT355_PRESENT_SLOTS)
+            return frames
+        finally:
+            dev.close()
+
+    sync_frames, async_frames = run(False), run(True)
+    assert len(async_frames) == 12
+    for k in range(12):
+        assert async_frames[k].shape == (size[1], size[0], 4)
+        assert np.array_equal(sync_frames[k], async_frames[k]), "frame %d differs" % k
+    ref = None
+    for k in range(12):
+        ref = oracle.render(scene.live_object_bytes(), len(scene.objects), scene.config_bytes(*size), (float(jit[k, 0]), float(jit[k, 1])), k,
+                            sky, rnd, history_rgba8=ref.rgba8 if ref else None)
+    assert np.array_equal(async_frames[11], ref.rgba8)

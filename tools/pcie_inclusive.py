@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive frame rate at the C-ABI boundary: render one 1080p frame, read its RGBA8 texels back to
-(pageable) host memory, every frame — what the reference's loop does when it shows each frame — with and
-without a fresh 600x600 random texture uploaded per frame (random_texture.rs:56-75 does so every 4 ms)."""
+"""PCIe-inclusive frame rate at the C-ABI boundary: render one 1080p frame and bring its RGBA8 texels to host memory, every
+frame — what the reference's loop does when it shows each frame (render_target.rs:50-70, app.rs:240-253):
+
+  * render only (no read-back): the rate to compare with;
+  * rt_present_async / rt_present_wait: frame k's copy into a pinned staging slot runs on a copy stream beside frame k + 1's
+    rendering (two slots alternate);
+  * rt_read_rgba8 into pageable host memory after every frame (blocking), with and without a fresh 600x600 random texture
+    uploaded per frame (random_texture.rs:56-75 does so every 4 ms).
+
+    python tools/pcie_inclusive.py [frames]"""
 import os
 import sys
 import time
@@ -24,7 +31,34 @@ rt.write(textures[0])
 scene = cases.headline_scene(8)
 conn = Connection(scene, dev, synth.procedural_skybox(2048, 1024), rt, max_objects="live")
 conn.update_buffers((W, H), scene, (0.0, 0.0))
-jit = synth.jitter_sequence(42, 256)
+FRAMES = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+jit = synth.jitter_sequence(42, 4096)
+
+
+def frame(k):
+    conn.frame_data.jitter, conn.frame_data.progressive_count = (float(jit[k % 4096, 0]), float(jit[k % 4096, 1])), k
+    conn.draw()
+
+
+rates = {}
+for mode in ("render only", "asynchronous presentation"):
+    for rep in range(3):
+        dev.sync()
+        t0 = time.perf_counter()
+        for k in range(FRAMES):
+            frame(k)
+            if mode != "render only":
+                target.present_async(k & 1)
+                if k:
+                    px = target.present_wait((k - 1) & 1, copy=False)  # the host "shows" frame k - 1 while frame k is copied
+        if mode != "render only":
+            px = target.present_wait((FRAMES - 1) & 1, copy=False)
+        dev.sync()
+        dt = (time.perf_counter() - t0) / FRAMES
+    st = dev.stats()
+    rates[mode] = st.last_segments / dt / 1e9
+    print("%-28s %.3f ms per frame = %.1f Grays/s, %.0f frames/s" % (mode + ":", dt * 1e3, rates[mode], 1.0 / dt))
+print("asynchronous presentation / render only = %.3f" % (rates["asynchronous presentation"] / rates["render only"]))
 for upload in (False, True):
     for rep in range(2):
         t0 = time.perf_counter()

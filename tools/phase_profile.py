@@ -77,5 +77,5 @@ if any(ev) and "events" in os.environ.get("RT355_LIB", ""):  # event-count build
               % (dmc[0], dmc[1] / dmc[0], dmc[3] / dmc[0], dmc[2] / max(dmc[3], 1)))
 if any(ev):
     print("  events of that launch: full scans tested %d spheres per wave-scan total, root + update taken for %d of them "
-          "(%.1f %%); cooperative scans %d sphere steps; listed (primary) scans %d spheres"
+          "(%.1f %%); cooperative scans %d sphere steps (candidate lists: rounds); listed (primary) scans %d spheres"
           % (ev[0], ev[1], 100.0 * ev[1] / max(ev[0], 1), ev[2], ev[3]))
