@@ -346,7 +346,11 @@ def main():
     single = slots80 = block_of_frames = None
     if not args.no_extra_legs:
         if B > 1:
-            single = leg_summary(reduce_leg(timed_leg(1, args.steps, 8, args.min_seconds / 2, 0.25)), 1)
+            # the same frames as a headline block (steps x B of them), one frame per launch and no timing-only events (a render loop
+            # does not ask for kernel times: RT_OPT_TIMING = 0)
+            dev.set_option(N.RT_OPT_TIMING, 0)
+            single = leg_summary(reduce_leg(timed_leg(1, args.steps, 8, args.min_seconds / 2, 0.25, frames_per_block=min(args.steps * B, 480))), 1)  # (the library keeps 512 launches of history)
+            dev.set_option(N.RT_OPT_TIMING, 1)
             # the protocol of rounds 1-2: a block = --steps FRAMES (B per launch), i.e. a few launches between two barriers
             old = reduce_leg(timed_leg(B, args.steps, 2, args.min_seconds / 4, 0.1, frames_per_block=args.steps))
             block_of_frames = {"frames_per_block": args.steps, "launches_per_block": old["block"]["launches"],
@@ -406,6 +410,10 @@ def main():
     b_alg = algorithmic_bytes(head["frame_px"] * n_frames, blk["seg"], blk["rough"])
     f_alg = algorithmic_flops(head["frame_px"] * n_frames, blk["seg"], n_objects)
     achieved = b_alg / k_sec / 1e9
+    frac_alg = f_alg / k_sec / 1e12 / VALU_PEAK_TFLOPS
+    hst = head["stats"]
+    structure = ("candidate lists, RT_OPT_DIRLIST" if hst.dirmask_lists else "direction-mask table, RT_OPT_DIRMASK") if hst.dirmask_cells else (
+        "sphere grid, RT_OPT_GRID_MIN" if hst.grid_cells else None)
     # Measured HBM traffic and issue utilisation are IMPORTED from the committed PMC passes (separate rocprofv3 --pmc
     # runs cannot happen inside this process): quoted only when the profile was collected on THIS workload, this launch
     # shape AND these kernel sources (sha256 over csrc/ + include/, recorded by tools/pmc_summary.py); null otherwise.
@@ -479,17 +487,24 @@ def main():
             "segments_per_pixel": round(head["total_seg"] / (float(W) * H * n_frames), 4),
             "mpixels_per_s": round(W * H * n_frames / elapsed / 1e6, 2),
         },
+        # The binding roofline of this path is the FP32 vector ALU (77 flop per algorithmic byte against a machine
+        # balance of ~20), so `roofline` is the VALU one; the HBM figures sit in roofline.hbm.
         "roofline": {
-            "bound": "hbm",
-            "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "achieved_basis": "algorithmic bytes (SURVEY.md 8d: 8 B/pixel + 16 B/segment + 8 B/rough hit) / HIP-event kernel time",
+            "bound": "valu",
+            "achieved": round(f_alg / k_sec / 1e12, 3),
+            "peak": VALU_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            # achieved / peak in units of the REFERENCE's algorithm (below): printed as `frac` only while it is a fraction
+            "frac": round(frac_alg, 5) if frac_alg <= 1.0 else None,
+            "frac_alg_reference_units_may_exceed_1": round(frac_alg, 5),
+            "issue_util": issue_util,  # the hardware view: SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x busy cycles), imported with `traffic`
+            "achieved_basis": "reference-equivalent flops: SURVEY.md 8d's F_alg = S (25 N + 200) + 60 P charges the reference's linear scan of "
+                              "all N objects (ray.hlsl:97-107) to every one of the S segments; / HIP-event kernel time.  %s"
+                              % ("These launches looked their candidates up (%s) and tested a few of the N, so this is speed in units of the "
+                                 "reference's algorithm, not ALU utilisation — it can exceed the peak; `issue_util` is the hardware's fraction."
+                                 % structure if structure else "These launches scanned every sphere for every secondary segment, as the reference does."),
             "traffic": traffic,
-            "traffic_resolve_kernel": traffic_resolve,
             "traffic_source": traffic_source,
-            "measured_gbs": round(traffic / (k_sec / launches) / 1e9, 2) if traffic else None,
             "kernel": kernel_name(head["stats"]),
             "avg_launch_ms": round(blk["kernel_ms"] / launches, 5),
             "launches_in_flight": args.batch_inflight if B > 1 else 4,
@@ -507,24 +522,27 @@ def main():
             "tail_avg_launch_ms": round(blk["tail_ms"] / launches, 5) if blk.get("tail_ms") else None,
             "resolve_avg_launch_ms": round(blk["resolve_ms"] / launches, 5),
             "launches": launches,
-            "alg_bytes_per_launch": round(b_alg / launches, 1),
-            "note": "VALU-bound path (SURVEY §8d): see 'valu' for the binding roofline",
-        },
-        "valu": {
-            "achieved": round(f_alg / k_sec / 1e12, 3),
-            "peak": VALU_PEAK_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": round(f_alg / k_sec / 1e12 / VALU_PEAK_TFLOPS, 5),
-            "issue_util": issue_util,  # imported with roofline.traffic (see traffic_source)
             "alg_flops_per_launch": round(f_alg / launches, 1),
             "kernel_mrays_per_s": round(blk["seg"] / k_sec / 1e6, 2),
             "scan_lane_occupancy": round(float(head["stats"].last_segments) / (64.0 * head["stats"].last_wave_iterations), 4)
             if head["stats"].last_wave_iterations else None,
-            "note": ("F_alg charges the reference's linear scan of every object to every segment; this launch walked the sphere "
-                     "grid and tested a fraction of them, so achieved/frac measure speed in units of the reference's algorithm, not "
-                     "ALU utilisation") if head["stats"].last_stage == 3 else None,
+            "alg_bytes_per_launch": round(b_alg / launches, 1),
+            "hbm": {
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "achieved_basis": "algorithmic bytes (SURVEY.md 8d: 8 B/pixel + 16 B/segment + 8 B/rough hit) / HIP-event kernel time",
+                "alg_bytes_per_launch": round(b_alg / launches, 1),
+                "traffic": traffic,
+                "traffic_resolve_kernel": traffic_resolve,
+                "measured_gbs": round(traffic / (k_sec / launches) / 1e9, 2) if traffic else None,
+            },
         },
     }
+    # (kept for the tools that read it: the same figures as `roofline`, which is the VALU roofline now)
+    out["valu"] = {k: out["roofline"][k] for k in ("achieved", "peak", "unit", "frac", "frac_alg_reference_units_may_exceed_1", "issue_util",
+                                                   "alg_flops_per_launch", "kernel_mrays_per_s", "scan_lane_occupancy", "achieved_basis")}
     if world == 1 and not args.no_cpu_baseline:
         import oracle
         rows = (0, H) if args.cpu_rows <= 0 else ((H - args.cpu_rows) // 2, (H - args.cpu_rows) // 2 + args.cpu_rows)

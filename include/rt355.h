@@ -370,6 +370,10 @@ enum {
   RT_OPT_DIRLIST_CELLS = 17,/* cells the lists' grid aims at (default 16384; cubic cells, at most 128 per axis)                  */
   RT_OPT_DIRLIST_K = 18,    /* their direction bins per cube-map face edge, 1..16 (default 8: 384 bins)                          */
   RT_OPT_DIRLIST_REACH = 19,/* the largest reach of an entry, in cells (default 16)                                             */
+  RT_OPT_TIMING = 20,       /* 1 (default): every launch records the HIP events rt_get_frame_history / rt_get_stats report kernel times from;
+                             * 0: single-frame launches in flight record none that only serve those queries (their kernel times read 0):
+                             * a frame then costs the host six HIP calls, 16 us instead of 27 (tools/microbench/host_calls.hip) — what a
+                             * render loop that never asks for kernel times wants when a rank's share of a frame is a few microseconds */
   RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 1): as RT_OPT_INFLIGHT,
                               each launch staging its samples in a buffer of its own; the history is updated in frame
                               order on the context's stream.  2 hides the resolve pass and the gap between launches

@@ -21,6 +21,7 @@ RT_OPT_DIRMASK, RT_OPT_DIRMASK_MIN, RT_OPT_DIRMASK_CELLS, RT_OPT_DIRMASK_K, RT_O
 RT355_PRESENT_SLOTS = 4
 RT_TAIL_SPILL_DEFAULT = 32  # kDefaultTailSpill (csrc/rt_device.h)
 RT_OPT_TAIL_SPILL_SINGLE = 14  # default 0
+RT_OPT_TIMING = 20
 RT_OPT_DIRLIST, RT_OPT_DIRLIST_MIN, RT_OPT_DIRLIST_CELLS, RT_OPT_DIRLIST_K, RT_OPT_DIRLIST_REACH = 15, 16, 17, 18, 19
 
 STATUS_NAMES = {0: "RT_OK", -1: "RT_ERR_INVALID_ARGUMENT", -2: "RT_ERR_NO_DEVICE", -3: "RT_ERR_NOT_READY",

@@ -230,6 +230,8 @@ int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n,
 // (device memory, zeroed by the caller) counts the cells whose near spheres did not fit the builder's list
 int launch_dirlist_build(const DirMaskParams &dm, const float4 *reg, uint32_t n, unsigned long long *table, uint32_t *d_overflow,
                          hipStream_t stream);
+// dst = src, `bytes` bytes (both 16-byte aligned), by a copy kernel on `stream`
+int launch_copy_texels(const void *src, void *dst, size_t bytes, hipStream_t stream);
 int launch_math_unary(int op, const float *x, float *y, size_t n, hipStream_t stream);
 int launch_math_binary(int op, const float *a, const float *b, float *y, size_t n, hipStream_t stream);
 

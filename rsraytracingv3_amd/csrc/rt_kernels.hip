@@ -2519,6 +2519,17 @@ __global__ void __launch_bounds__(256) assemble_strips_kernel(AssembleParams ap)
   ap.frame[i] = r == 0u ? ap.own[src] : ap.stack[ap.stack_offset[r] + src];
 }
 
+// Snapshot of a frame's texels for the asynchronous presentation (rt_present_async): a plain 16-bytes-per-lane copy on the stream
+// that produced the frame — microseconds at HBM rate, where a hipMemcpyAsync between device buffers may take the DMA engine the
+// host copies run on.
+__global__ void __launch_bounds__(256) copy_texels_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16,
+                                                          const unsigned char *__restrict__ src_tail, unsigned char *__restrict__ dst_tail,
+                                                          uint32_t n_tail) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * 256u;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * 256u + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x < n_tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 // Device-side refill of the random texture: the reference regenerates 600x600
 // uniform floats on a host thread every 4 ms and uploads them (random_texture.rs:56-75, ~360 MB/s of
 // PCIe); here texel k (row-major) is SplitMix64 output k+1 of `seed`, top 24 bits -> [0,1) on the
@@ -2848,6 +2859,17 @@ int persistent_blocks_per_cu(size_t lds_bytes) {
 int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream) {
   if (count == 0) return 0;
   hipLaunchKernelGGL(random_fill_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, dst, count, seed);
+  return static_cast<int>(hipGetLastError());
+}
+
+int launch_copy_texels(const void *src, void *dst, size_t bytes, hipStream_t stream) {
+  if (bytes == 0) return 0;
+  const size_t n16 = bytes / 16u;
+  const uint32_t tail = static_cast<uint32_t>(bytes - n16 * 16u);
+  const size_t want = (n16 + 1023u) / 1024u;  // four 16-byte words per thread
+  const uint32_t blocks = static_cast<uint32_t>(want < 1u ? 1u : (want > 4096u ? 4096u : want));
+  hipLaunchKernelGGL(copy_texels_kernel, dim3(blocks), dim3(256), 0, stream, static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16,
+                     static_cast<const unsigned char *>(src) + n16 * 16u, static_cast<unsigned char *>(dst) + n16 * 16u, tail);
   return static_cast<int>(hipGetLastError());
 }
 

@@ -93,6 +93,8 @@ struct rt_context {
   uint32_t tail_occupancy_records = 0;
   bool tail_occupancy_lists = false;
   int flags = 0;            // RT_OPT_FLAGS
+  int timing = 1;           // RT_OPT_TIMING: 0 = single-frame launches in flight record no timing-only events
+  std::vector<unsigned char> timed;  // the launch in that ring slot recorded its start event
   int cull = 1;             // RT_OPT_CULL: 0 off, 1 on, 2 on + self-check against the full scan
   unsigned long long *d_masks = nullptr;  // per-tile sphere masks of the primary-ray culling
   size_t masks_cap = 0;     // in 64-bit words
@@ -516,6 +518,7 @@ int rt_create(int device_id, rt_context **out_ctx) {
   ctx->ev_resolved.assign(rt_context::kRing, nullptr);
   ctx->ev_tail.assign(rt_context::kRing, nullptr);
   ctx->tail_ran.assign(rt_context::kRing, 0);
+  ctx->timed.assign(rt_context::kRing, 0);
   for (uint32_t i = 0; i < rt_context::kRing; ++i)
     if (hipEventCreate(&ctx->ev_start[i]) != hipSuccess || hipEventCreate(&ctx->ev_stop[i]) != hipSuccess ||
         hipEventCreate(&ctx->ev_resolved[i]) != hipSuccess || hipEventCreate(&ctx->ev_tail[i]) != hipSuccess)
@@ -636,7 +639,10 @@ int rt_set_random(rt_context *ctx, uint32_t width, uint32_t height, const float 
     std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
     target = (ctx->rnd_cur == 0) ? 1 : 0;
     wait_use = ctx->rnd_used[target];
-    if (wait_use && hipStreamWaitEvent(ctx->upload_stream, ctx->rnd_last_use[target], 0) != hipSuccess)
+    // every launch that read `target` has been joined to the context's stream by now (render_frames queues the join before it
+    // releases the lock), and no later launch reads it before it is published below: an event recorded here is its last use
+    if (wait_use && (hipEventRecord(ctx->rnd_last_use[target], ctx->stream) != hipSuccess ||
+                     hipStreamWaitEvent(ctx->upload_stream, ctx->rnd_last_use[target], 0) != hipSuccess))
       return RT_ERR_DEVICE;
   }
   if (ctx->rnd_cap[target] < bytes) {
@@ -674,7 +680,10 @@ int rt_generate_random(rt_context *ctx, uint32_t width, uint32_t height, uint64_
     std::lock_guard<std::mutex> lk(ctx->rnd_mutex);
     target = (ctx->rnd_cur == 0) ? 1 : 0;
     wait_use = ctx->rnd_used[target];
-    if (wait_use && hipStreamWaitEvent(ctx->upload_stream, ctx->rnd_last_use[target], 0) != hipSuccess)
+    // every launch that read `target` has been joined to the context's stream by now (render_frames queues the join before it
+    // releases the lock), and no later launch reads it before it is published below: an event recorded here is its last use
+    if (wait_use && (hipEventRecord(ctx->rnd_last_use[target], ctx->stream) != hipSuccess ||
+                     hipStreamWaitEvent(ctx->upload_stream, ctx->rnd_last_use[target], 0) != hipSuccess))
       return RT_ERR_DEVICE;
   }
   if (ctx->rnd_cap[target] < bytes) {
@@ -1396,6 +1405,9 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       if (value < 1 || value > 128) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_DIRLIST_REACH takes 1..128");
       ctx->dirlist_reach = value;
       return RT_OK;
+    case RT_OPT_TIMING:
+      ctx->timing = value != 0;
+      return RT_OK;
     case RT_OPT_TAIL_SPILL:
       if (value < 0 || value > 128) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TAIL_SPILL takes 0..128");
       ctx->tail_spill = value;
@@ -1751,7 +1763,9 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->present_done[ctx->present_guard], 0));
     ctx->present_guard = -1;
   }
-  RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], render_stream));
+  // (the start event only serves the timing queries: single-frame launches in flight may go without, RT_OPT_TIMING = 0)
+  ctx->timed[slot] = (ctx->timing != 0 || !pipelined || batch > 1u) ? 1 : 0;
+  if (ctx->timed[slot]) RT_HIP(ctx, hipEventRecord(ctx->ev_start[slot], render_stream));
   int per_cu = ctx->blocks_per_cu;
   if (per_cu <= 0 && ctx->variant == 2) {  // only the resident-wave shape sizes its grid by occupancy
     if (ctx->occupancy_records != ctx->scene.image_records) {
@@ -1768,8 +1782,7 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   RT_HIP(ctx, hipEventRecord(ctx->ev_stop[slot], render_stream));
   if (pipelined)  // the main stream joins the renders in frame order: everything after this point sees frame k done
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_stop[slot], 0));
-  RT_HIP(ctx, hipEventRecord(ctx->rnd_last_use[rnd], ctx->stream));
-  ctx->rnd_used[rnd] = true;
+  ctx->rnd_used[rnd] = true;  // (rt_set_random records the copy's last use itself, when it is about to refill it)
   rnd_lock.unlock();
   if (staging != nullptr && launch_resolve(rp, ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "resolve launch failed");
   RT_HIP(ctx, hipEventRecord(ctx->ev_resolved[slot], ctx->stream));
@@ -1902,7 +1915,7 @@ static int present_from(rt_context *ctx, uint32_t slot, const void *src, size_t 
       RT_HIP(ctx, hipMalloc(&ctx->d_present[slot], bytes));
       ctx->present_dev_cap[slot] = bytes;
     }
-    RT_HIP(ctx, hipMemcpyAsync(ctx->d_present[slot], src, bytes, hipMemcpyDeviceToDevice, producer));
+    if (launch_copy_texels(src, ctx->d_present[slot], bytes, producer) != 0) return fail(ctx, RT_ERR_DEVICE, "rt_present_async: the snapshot launch failed");
     from = ctx->d_present[slot];
   }
   if (copier != producer) {
@@ -1910,6 +1923,7 @@ static int present_from(rt_context *ctx, uint32_t slot, const void *src, size_t 
     RT_HIP(ctx, hipEventRecord(ctx->present_ready, producer));
     RT_HIP(ctx, hipStreamWaitEvent(copier, ctx->present_ready, 0));
   }
+  // (the DMA engine: a kernel storing into the pinned buffer instead moves 29 GB/s beside the rendering where this moves 41)
   RT_HIP(ctx, hipMemcpyAsync(ctx->present_host[slot], from, bytes, hipMemcpyDeviceToHost, copier));
   RT_HIP(ctx, hipEventRecord(ctx->present_done[slot], copier));
   ctx->present_bytes[slot] = bytes;
@@ -2021,7 +2035,7 @@ int rt_get_stats(rt_context *ctx, rt_stats *out) {
     ctx->stats.last_rough_hits = c[1];
     ctx->stats.last_wave_iterations = c[2];
     float ms = 0.0f;
-    RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
+    if (ctx->timed[slot]) RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start[slot], ctx->ev_stop[slot]));
     ctx->stats.last_kernel_ms = ms;
     RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_stop[slot], ctx->ev_resolved[slot]));
     ctx->stats.last_resolve_ms = ms;
@@ -2075,7 +2089,10 @@ int rt_get_frame_history(rt_context *ctx, uint32_t n, uint64_t *segments, uint64
     }
     if (segments) segments[k] = c[0];
     if (rough_hits) rough_hits[k] = c[1];
-    if (kernel_ms) RT_HIP(ctx, hipEventElapsedTime(&kernel_ms[k], ctx->ev_start[slot], ctx->ev_stop[slot]));
+    if (kernel_ms) {
+      kernel_ms[k] = 0.0f;  // (a launch without timing events, RT_OPT_TIMING = 0)
+      if (ctx->timed[slot]) RT_HIP(ctx, hipEventElapsedTime(&kernel_ms[k], ctx->ev_start[slot], ctx->ev_stop[slot]));
+    }
   }
   return RT_OK;
 }
@@ -2118,7 +2135,8 @@ int rt_get_launch_span(rt_context *ctx, uint32_t n, float *span_ms) {
   RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t first = static_cast<uint32_t>((ctx->stats.frames - n) % rt_context::kRing);
   const uint32_t last = static_cast<uint32_t>((ctx->stats.frames - 1) % rt_context::kRing);
-  RT_HIP(ctx, hipEventElapsedTime(span_ms, ctx->ev_start[first], ctx->ev_stop[last]));
+  *span_ms = 0.0f;
+  if (ctx->timed[first]) RT_HIP(ctx, hipEventElapsedTime(span_ms, ctx->ev_start[first], ctx->ev_stop[last]));
   return RT_OK;
 }
 

@@ -41,24 +41,27 @@ def frame(k):
 
 
 rates = {}
-for mode in ("render only", "asynchronous presentation"):
+for mode, depth in (("render only", 0), ("asynchronous presentation, 1 frame ahead", 1), ("asynchronous presentation, 2 frames ahead", 2),
+                    ("asynchronous presentation, 3 frames ahead", 3)):
+    slots = depth + 1  # the host shows frame k - depth while frames k - depth + 1 .. k are rendered and copied
     for rep in range(3):
         dev.sync()
         t0 = time.perf_counter()
         for k in range(FRAMES):
             frame(k)
-            if mode != "render only":
-                target.present_async(k & 1)
-                if k:
-                    px = target.present_wait((k - 1) & 1, copy=False)  # the host "shows" frame k - 1 while frame k is copied
-        if mode != "render only":
-            px = target.present_wait((FRAMES - 1) & 1, copy=False)
+            if depth:
+                target.present_async(k % slots)
+                if k >= depth:
+                    px = target.present_wait((k - depth) % slots, copy=False)
+        for k in range(max(FRAMES - depth, 0), FRAMES):
+            if depth:
+                px = target.present_wait(k % slots, copy=False)
         dev.sync()
         dt = (time.perf_counter() - t0) / FRAMES
     st = dev.stats()
     rates[mode] = st.last_segments / dt / 1e9
-    print("%-28s %.3f ms per frame = %.1f Grays/s, %.0f frames/s" % (mode + ":", dt * 1e3, rates[mode], 1.0 / dt))
-print("asynchronous presentation / render only = %.3f" % (rates["asynchronous presentation"] / rates["render only"]))
+    print("%-44s %.3f ms per frame = %.1f Grays/s, %.0f frames/s%s" % (mode + ":", dt * 1e3, rates[mode], 1.0 / dt,
+          "  (%.1f GB/s of texels, %.2f of the render-only rate)" % (W * H * 4 / dt / 1e9, rates[mode] / rates["render only"]) if depth else ""))
 for upload in (False, True):
     for rep in range(2):
         t0 = time.perf_counter()
