@@ -80,6 +80,10 @@ typedef struct rt_stats {
   uint32_t grid_cells, grid_items; /* the current scene's sphere grid (0 = none: small scene, or not buildable) */
   uint32_t dirmask_cells, dirmask_bins; /* the current scene's direction-mask table (RT_OPT_DIRMASK) or candidate-list table
                                            (RT_OPT_DIRLIST): cells and direction bins per cell; 0 = none              */
+  uint32_t tail_spill_unavailable; /* 1: a launch wanted to spill its tail (RT_OPT_TAIL_SPILL) but the path queue could not be allocated —
+                                      it rendered without the spill (same frame, slower); 0 otherwise                          */
+  uint64_t path_queue_bytes;  /* device memory the context's path queues hold right now (freed by rt_resize / rt_set_partition;
+                                 a launch that spills allocates what it needs, at most 1 GiB)                              */
   uint32_t dirmask_lists;     /* 0: the table holds bit sets (scenes of up to 128 spheres); otherwise it holds candidate lists
                                  (larger scenes) and this is the largest reach of an entry, in cells                    */
 } rt_stats;
@@ -203,6 +207,11 @@ typedef struct rt_multi rt_multi;
 RT355_API int rt_multi_create(const int *device_ids, uint32_t n_devices, uint32_t strip_rows, rt_multi **out);
 RT355_API int rt_multi_destroy(rt_multi *m);
 RT355_API uint32_t rt_multi_device_count(rt_multi *m);
+/* How the gather reaches the first device: members on another device with direct peer access to it (hipDeviceEnablePeerAccess: one
+ * xGMI hop per strip) and members whose copies the runtime stages (no peer access: slower, still correct).  Members on the first
+ * device itself count in neither.  NOTE: this environment has one GPU per box — the cross-device path has never run on two physical
+ * devices (tests bind one device several times); tests/test_multi_gpu.py holds a test that runs only where two are visible. */
+RT355_API int rt_multi_peer_status(rt_multi *m, uint32_t *direct, uint32_t *staged);
 RT355_API rt_context *rt_multi_context(rt_multi *m, uint32_t index);
 RT355_API const char *rt_multi_last_error(rt_multi *m);
 RT355_API int rt_multi_set_skybox(rt_multi *m, uint32_t width, uint32_t height, const float *rgba32f);
@@ -329,8 +338,11 @@ enum {
   RT_OPT_BLOCKS_PER_CU = 2,/* variants 2 and 4: resident workgroups per CU (0 = occupancy query) */
   RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump; variant 4: 64-path
                               units a wave takes off the path queue at a time */
-  RT_OPT_FLAGS = 4,        /* experiment switches (speed only): bit 1 (2) ignore the sphere grid; bit 2 (4) launches of every
-                              size spill their tail (RT_OPT_TAIL_SPILL)                             */
+  RT_OPT_FLAGS = 4,        /* experiment switches: bit 1 (2) ignore the sphere grid; bit 2 (4) launches of every size spill their
+                              tail (RT_OPT_TAIL_SPILL) — speed only, frames stay bit-identical; bit 4 (16) DRY launches: every
+                              kernel of a launch (render, tail, resolve, assembly) runs ONE workgroup and peer copies move one row —
+                              all of a frame's host calls, events and stream waits with next to none of its device work, to tell
+                              host time from device time (tools/multi_times.py); the frames are garbage                         */
   RT_OPT_CULL = 5,         /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
                               scan is re-done in full and disagreements are counted in rt_stats     */
   RT_OPT_INFLIGHT = 6,     /* single-frame launches (rt_render / rt_render_frame) in flight at once, 1..8 (default 4):
@@ -355,11 +367,12 @@ enum {
                              * which only pays in long uninterrupted runs of frames (+1..2 %)                              */
   RT_OPT_TAIL_SPILL = 13,   /* multi-frame launches (rt_render_frames) of the re-packing shape, of 100 000 tiles or more (three
                              * 1080p frames) and two bounces or more, on a scene with a direction-mask table: a workgroup whose paths that hit number at most
-                             * this many (0..128, default 32; 0 = off) hands them — path state + pending hit, 80 B — to a path
+                             * this many (0..128; -1 = the default: 32, 24 on a scene with candidate lists; 0 = off) hands them — path state + pending hit, 80 B — to a path
                              * queue in device memory and ends; a second kernel, tail_stream, takes them up into full waves for
                              * their remaining bounces instead of letting each workgroup bounce its last few paths on in a
                              * mostly empty wave (bit-identical; +5 % at 1080p, +9 % at 3840x2160).  The queue holds at most
-                             * workgroups x threshold records (0.33 GB for 8 frames of 1080p); above 4 GiB the threshold shrinks */
+                             * workgroups x threshold records (0.33 GB for 8 frames of 1080p); above 1 GiB the threshold shrinks; rt_stats reports the
+                             * queue's size and a launch that had to go without it */
   RT_OPT_DIRLIST = 15,      /* 1 (default): scenes of RT_OPT_DIRLIST_MIN spheres or more (up to 65 535) receive a table of candidate
                              * LISTS at the next rt_set_scene instead of the sphere grid: [cell of the point a ray has reached][bin of
                              * its direction] -> up to 15 sphere slots + the distance up to which the list is complete (its reach);
@@ -368,8 +381,8 @@ enum {
                              * LDS.  0: off (the grid of RT_OPT_GRID_MIN serves).  RT_OPT_DIRMASK = 0 switches both tables off.      */
   RT_OPT_DIRLIST_MIN = 16,  /* fewest spheres that get candidate lists (default 129: the bit-set table serves up to 128)          */
   RT_OPT_DIRLIST_CELLS = 17,/* cells the lists' grid aims at (default 16384; cubic cells, at most 128 per axis)                  */
-  RT_OPT_DIRLIST_K = 18,    /* their direction bins per cube-map face edge, 1..16 (default 8: 384 bins)                          */
-  RT_OPT_DIRLIST_REACH = 19,/* the largest reach of an entry, in cells (default 16)                                             */
+  RT_OPT_DIRLIST_K = 18,    /* their direction bins per cube-map face edge, 1..16 (default 10: 600 bins)                           */
+  RT_OPT_DIRLIST_REACH = 19,/* the largest reach of an entry, in cells (default 32)                                             */
   RT_OPT_TIMING = 20,       /* 1 (default): every launch records the HIP events rt_get_frame_history / rt_get_stats report kernel times from;
                              * 0: single-frame launches in flight record none that only serve those queries (their kernel times read 0):
                              * a frame then costs the host six HIP calls, 16 us instead of 27 (tools/microbench/host_calls.hip) — what a

@@ -19,7 +19,7 @@ RT_OPT_VARIANT, RT_OPT_REFILL_MIN, RT_OPT_BLOCKS_PER_CU, RT_OPT_TILE_CHUNK, RT_O
 RT_OPT_INFLIGHT, RT_OPT_GRID_MIN, RT_OPT_BATCH_INFLIGHT = 6, 7, 8
 RT_OPT_DIRMASK, RT_OPT_DIRMASK_MIN, RT_OPT_DIRMASK_CELLS, RT_OPT_DIRMASK_K, RT_OPT_TAIL_SPILL = 9, 10, 11, 12, 13
 RT355_PRESENT_SLOTS = 4
-RT_TAIL_SPILL_DEFAULT = 32  # kDefaultTailSpill (csrc/rt_device.h)
+RT_TAIL_SPILL_DEFAULT = -1  # the default of the scene's kind (kDefaultTailSpill 32, kDefaultTailSpillLists 24: csrc/rt_device.h)
 RT_OPT_TAIL_SPILL_SINGLE = 14  # default 0
 RT_OPT_TIMING = 20
 RT_OPT_DIRLIST, RT_OPT_DIRLIST_MIN, RT_OPT_DIRLIST_CELLS, RT_OPT_DIRLIST_K, RT_OPT_DIRLIST_REACH = 15, 16, 17, 18, 19
@@ -42,7 +42,8 @@ class RtStats(C.Structure):
                 ("last_wave_iterations", C.c_uint64), ("last_cull_mismatches", C.c_uint64),
                 ("last_resolve_ms", C.c_float), ("last_variant", C.c_uint32), ("last_stage", C.c_uint32),
                 ("grid_cells", C.c_uint32), ("grid_items", C.c_uint32),
-                ("dirmask_cells", C.c_uint32), ("dirmask_bins", C.c_uint32), ("dirmask_lists", C.c_uint32)]
+                ("dirmask_cells", C.c_uint32), ("dirmask_bins", C.c_uint32), ("tail_spill_unavailable", C.c_uint32),
+                ("path_queue_bytes", C.c_uint64), ("dirmask_lists", C.c_uint32)]
 
 
 class RtGridInfo(C.Structure):
@@ -103,6 +104,7 @@ SIGNATURES = {
     "rt_multi_create": (_i, [C.POINTER(C.c_int), _u32, _u32, C.POINTER(_vp)]),
     "rt_multi_destroy": (_i, [_vp]),
     "rt_multi_device_count": (_u32, [_vp]),
+    "rt_multi_peer_status": (_i, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "rt_multi_context": (_vp, [_vp, _u32]),
     "rt_multi_last_error": (C.c_char_p, [_vp]),
     "rt_multi_set_skybox": (_i, [_vp, _u32, _u32, _vp]),
@@ -204,7 +206,10 @@ def load():
                 "There is no CPU fallback." % LIB_PATH)
         _preload_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
+        host_only = os.environ.get("RT355_HOST_ONLY") == "1"  # the sanitizer build of the host code (make host-asan): no device entry points
         for name, (res, args) in SIGNATURES.items():
+            if host_only and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

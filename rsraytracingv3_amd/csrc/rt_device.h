@@ -77,8 +77,10 @@ constexpr int kDefaultDirmaskMinSpheres = 26;  // RT_OPT_DIRMASK_MIN
 constexpr int kDefaultDirmaskCells = 4096;     // RT_OPT_DIRMASK_CELLS
 constexpr int kDefaultDirmaskK = 12;           // RT_OPT_DIRMASK_K
 constexpr int kDefaultDirlistCells = 16384;    // RT_OPT_DIRLIST_CELLS: cells aimed at by the candidate lists of large scenes
-constexpr int kDefaultDirlistK = 8;            // RT_OPT_DIRLIST_K: their bins per face edge
-constexpr int kDefaultDirlistReach = 16;       // RT_OPT_DIRLIST_REACH: the largest reach of an entry, in cells
+constexpr int kDefaultDirlistK = 10;           // RT_OPT_DIRLIST_K: their bins per face edge (A/B on one device at 1 024 spheres, reach 32: k = 6 / 8 / 10 / 12
+                                               // 35.6 / 36.2 / 36.6 / 36.6 Grays/s; the table takes 164 / 292 / 456 / 657 MB)
+constexpr int kDefaultDirlistReach = 32;       // RT_OPT_DIRLIST_REACH: the largest reach of an entry, in cells (16 / 32: 36.0 / 36.6)
+constexpr int kDefaultTailSpillLists = 24;     // RT_OPT_TAIL_SPILL of scenes with candidate lists (one-wave workgroups: 16 / 24 / 32: 37.7 / 37.8 / 37.4)
 constexpr int kDefaultGridMinSpheres = 129;    // RT_OPT_GRID_MIN
 constexpr int kDefaultInflight = 4;            // RT_OPT_INFLIGHT
 constexpr int kDefaultBatchInflight = 1;       // RT_OPT_BATCH_INFLIGHT
@@ -202,7 +204,7 @@ int stream_blocks_per_cu(size_t lds_bytes);
 // Tail spill (FrameParams::spill_max): the threshold this launch would run with when `wanted` is asked for (0: the launch
 // shape, the scene or the queue budget rule it out) and the records per queue shard it needs (five float4 planes of
 // kQueueShards shards); resident workgroups per CU of tail_stream.
-constexpr size_t kTailQueueBudget = 4ull << 30;  // bytes of queue a launch may ask for; the threshold shrinks to fit
+constexpr size_t kTailQueueBudget = 1ull << 30;  // bytes of queue a launch may ask for; the threshold shrinks to fit (8 frames of 4K at the default threshold: 1.33 GB -> 24)
 constexpr uint64_t kTailMinTiles = 100000;       // 8x8 tiles from which a launch spills (1080p: 2 frames per launch 42.8 Grays/s without /
                                                  // 41.0 with the spill, 4 frames 47.6 / 48.7, 8 frames 50.2 / 52.2: from three frames up)
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap);
@@ -212,7 +214,7 @@ int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipS
 int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, hipStream_t stream,
                   int *variant_used = nullptr, int *stage_used = nullptr);  // the launch shape chosen (0..3) and what
                                                                             // it staged into LDS (render_tiles<STAGE>)
-int launch_resolve(const ResolveParams &rp, hipStream_t stream);
+int launch_resolve(const ResolveParams &rp, hipStream_t stream, bool dry = false);  // dry: one workgroup (RT_OPT_FLAGS bit 4)
 // rank 0 of a multi-GPU frame: interleave the row strips of all ranks (own buffer + the peers' buffers received
 // into `stack`, rank r's rows at texel offset stack_offset[r]) into the height x width frame
 constexpr uint32_t kMaxRanks = 64;
@@ -222,7 +224,7 @@ struct AssembleParams {
   uint32_t width, height, world, strip_rows;
   uint32_t stack_offset[kMaxRanks];  // in texels; [0] unused
 };
-int launch_assemble(const AssembleParams &ap, hipStream_t stream);
+int launch_assemble(const AssembleParams &ap, hipStream_t stream, bool dry = false);
 int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned long long *masks, hipStream_t stream);
 // fills dm.table ([cells][bins] 64-bit sets) from the n registered spheres reg[] = {c, r_reg} (device memory)
 int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n, unsigned long long *table, hipStream_t stream);

@@ -63,6 +63,13 @@ namespace {
 #ifndef RT_LIST_TRIPS2
 #define RT_LIST_TRIPS2 1  // candidate-list scan: two (ray, sphere) pairs per lane and trip, their dependent reads in flight together
 #endif
+#ifndef RT_LIST_NT_LOADS
+#define RT_LIST_NT_LOADS 0  // 1 = candidate-list entries loaded with the non-temporal hint: A/B on one device 32.4 against 36.1 Grays/s at 1 024 spheres —
+                            // neighbouring rays share entries, and a streamed line is gone when the next one asks
+#endif
+#ifndef RT_LIST_LDS_COUNTER
+#define RT_LIST_LDS_COUNTER 0  // pair positions from one LDS atomic per lane instead of a DPP prefix sum
+#endif
 #ifndef RT_LIST_EARLY_X
 #define RT_LIST_EARLY_X 1  // kernels of large scenes: the shading's random() texels requested around the scan
 #endif
@@ -109,10 +116,14 @@ constexpr int kTile = 8;  // 8x8 pixels per tile / wave
 #ifndef RT_PACK_HITS
 #define RT_PACK_HITS 1  // re-packing shape: pack the paths that hit between the scan and the shading (0: after the shading)
 #endif
-#ifndef RT_XCHG_PATHS
-#define RT_XCHG_PATHS ((RT_BLOCK_NW - 1) * 64)  // re-packing needs the paths to fit one wave fewer
+#ifndef RT_BLOCK_NW_LISTS
+#define RT_BLOCK_NW_LISTS 1  // ... of the kernels of large scenes (candidate lists, nothing staged): ONE wave.  Two waves share a staged scene
+                             // image and re-pack their paths; without the image the count barrier and the re-packing only cost (a fifth
+                             // of the waves' time: a wave that needs a second round of lookups holds its partner at the barrier), and the
+                             // tail spill takes the thinned-out wave's paths anyway.  A/B on one device, 1 024 spheres: 37.4 against 35.8
+                             // Grays/s (at 64 spheres, staged: 48.9 against 54.0 — hence two there)
 #endif
-constexpr uint32_t kXchgPaths = RT_XCHG_PATHS;  // paths the block kernel's LDS exchange buffer holds
+constexpr uint32_t xchg_paths(uint32_t nw) { return (nw - 1u) * 64u; }  // paths the exchange buffer holds: re-packing needs them to fit one wave fewer
 #ifndef RT_BALANCED_SCAN
 #define RT_BALANCED_SCAN 1  // direction-mask scans of the re-packing shape: 1 = the wave's (ray, candidate) pairs are dealt evenly over
                             // its lanes through LDS instead of every lane walking its own set (trips = the wave's heaviest lane)
@@ -124,16 +135,16 @@ constexpr uint32_t kScanScratchBytes = 64u * 16u + 64u * 8u + 64u * 8u + kPairCa
 // entries as loaded, and up to 64 x 15 (lane, position) pairs
 constexpr uint32_t kListPairCap = 64u * kDirListSlots;
 constexpr uint32_t kListScratchBytes = 64u * 16u + 64u * 8u + 64u * 8u + 64u * 32u + kListPairCap * 2u;  // 6016
-constexpr uint32_t kXchgBytes = kXchgPaths * (RT_PACK_HITS ? 5u : 4u) * 16u;
+constexpr uint32_t xchg_bytes(uint32_t nw) { return xchg_paths(nw) * (RT_PACK_HITS ? 5u : 4u) * 16u; }
 // With two waves per workgroup the scratch may share the exchange buffer's LDS: the buffer is only written after a count
 // barrier that both waves reach after their scans, and once it has been used a single wave is left.  Other workgroup sizes
 // keep the two apart.
-constexpr bool kScratchInXchg = RT_BLOCK_NW == 2;
-constexpr uint32_t kBlocksLdsExtra = !RT_BALANCED_SCAN ? kXchgBytes
-                                     : (kScratchInXchg ? (kXchgBytes > RT_BLOCK_NW * kScanScratchBytes ? kXchgBytes : RT_BLOCK_NW * kScanScratchBytes)
-                                                       : kXchgBytes + RT_BLOCK_NW * kScanScratchBytes);
-constexpr uint32_t kBlocksLdsExtraLists = kScratchInXchg ? (kXchgBytes > RT_BLOCK_NW * kListScratchBytes ? kXchgBytes : RT_BLOCK_NW * kListScratchBytes)
-                                                         : kXchgBytes + RT_BLOCK_NW * kListScratchBytes;
+constexpr bool scratch_in_xchg(uint32_t nw) { return nw <= 2u; }
+constexpr uint32_t blocks_lds_extra(uint32_t nw, uint32_t scratch_bytes) {
+  return scratch_in_xchg(nw) ? (xchg_bytes(nw) > nw * scratch_bytes ? xchg_bytes(nw) : nw * scratch_bytes) : xchg_bytes(nw) + nw * scratch_bytes;
+}
+constexpr uint32_t kBlocksLdsExtra = !RT_BALANCED_SCAN ? xchg_bytes(RT_BLOCK_NW) : blocks_lds_extra(RT_BLOCK_NW, kScanScratchBytes);
+constexpr uint32_t kBlocksLdsExtraLists = blocks_lds_extra(RT_BLOCK_NW_LISTS, kListScratchBytes);
 
 // Correctly rounded sqrt for x >= 2^-96 (also +0, +inf, NaN): v_sqrt_f32 is within 1 ulp, so
 // the IEEE result is one of {s-1ulp, s, s+1ulp}; the signs of the two fused residuals pick it
@@ -844,7 +855,23 @@ __device__ __forceinline__ SphereHit scan_grid(const SceneView &sv, const GridPa
   return SphereHit{best_key, best_slot};
 }
 
+// A 16-byte record of the scene image read at a wave-uniform address.  CONST = the record lives in device memory (the kernels of
+// large scenes stage nothing): it is read through the constant address space — the image is never written by a kernel —, which
+// makes it a SCALAR load: it does not queue up behind the wave's vector loads (a vector load here would wait, at its
+// s_waitcnt vmcnt(0), for the candidate-list entry requested just before it), and it returns into scalar registers.
+template <bool CONST>
+__device__ __forceinline__ float4 load_record(const float4 *p) {
+  if (CONST) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(4))) f32x4 *q = (const __attribute__((address_space(4))) f32x4 *)(p);
+    const f32x4 v = *q;
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+  return *p;
+}
+
 // The rest of ray.hlsl:97-107: sphere result -> Hit, then the planes (ray.hlsl:69-94).
+template <bool CONST = false>
 __device__ __forceinline__ Hit finish_hit(const SceneView &sv, SphereHit sh, f3 o, f3 d) {
   const float best = __uint_as_float(sh.key + kEpsBits);
   const int slot = sh.slot;
@@ -854,7 +881,7 @@ __device__ __forceinline__ Hit finish_hit(const SceneView &sv, SphereHit sh, f3 
   h.plane = false;
   h.obj = (slot >= 0) ? sv.sph_obj[slot] : -1;
   for (uint32_t j = 0; j < sv.n_pl; ++j) {
-    const float4 a = sv.pl_a[j], b = sv.pl_b[j];
+    const float4 a = load_record<CONST>(sv.pl_a + j), b = load_record<CONST>(sv.pl_b + j);
     const f3 c = mk3(a.x, a.y, a.z), nrm = mk3(b.x, b.y, b.z);
     const int idx = static_cast<int>(f2u(b.w));
     const float den = dot3(d, nrm);
@@ -878,6 +905,7 @@ __device__ __forceinline__ Hit finish_hit(const SceneView &sv, SphereHit sh, f3 
 // The plane part of ray.hlsl:97-107 on its own (ray.hlsl:69-94), and its merge with the sphere result: the same
 // lexicographic (distance, object index) minimum finish_hit builds, in another order — so that the planes can be tested
 // while the ray's candidate set is still on its way from memory (dirmask_lookup).
+template <bool CONST = false>
 __device__ __forceinline__ Hit nearest_plane(const SceneView &sv, f3 o, f3 d) {
   Hit h;
   h.t = 1000000.0f;  // ray.hlsl:98: the initial hit.distance
@@ -885,7 +913,7 @@ __device__ __forceinline__ Hit nearest_plane(const SceneView &sv, f3 o, f3 d) {
   h.slot = -1;
   h.plane = false;
   for (uint32_t j = 0; j < sv.n_pl; ++j) {
-    const float4 a = sv.pl_a[j], b = sv.pl_b[j];
+    const float4 a = load_record<CONST>(sv.pl_a + j), b = load_record<CONST>(sv.pl_b + j);
     const f3 c = mk3(a.x, a.y, a.z), nrm = mk3(b.x, b.y, b.z);
     const int idx = static_cast<int>(f2u(b.w));
     const float den = dot3(d, nrm);
@@ -1048,9 +1076,17 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     }
     const f3 p = fma3(d, s, o);
     const uint32_t entry = todo ? dirmask_cell(dm, p) * dm.bins + bin : dm.entries;  // lanes without a lookup read the zero entry
+#if RT_LIST_NT_LOADS
+    // (streamed: an entry is read once — it should not push the sphere records and materials out of the caches)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *tv = reinterpret_cast<const u32x4 *>(table) + 2u * static_cast<size_t>(entry);
+    const u32x4 v0 = __builtin_nontemporal_load(tv), v1 = __builtin_nontemporal_load(tv + 1);
+    const uint4 w0 = make_uint4(v0.x, v0.y, v0.z, v0.w), w1 = make_uint4(v1.x, v1.y, v1.z, v1.w);
+#else
     const uint4 w0 = table[2u * static_cast<size_t>(entry)], w1 = table[2u * static_cast<size_t>(entry) + 1u];
+#endif
     if (planes_pending) {  // wave-uniform: the first round
-      if (alive) hp = nearest_plane(sv, o, d);
+      if (alive) hp = nearest_plane<true>(sv, o, d);
       planes_pending = false;
     }
     RT_PHL_WAIT
@@ -1155,7 +1191,7 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     }
   }
   RT_PHL(4)
-  if (planes_pending && alive) hp = nearest_plane(sv, o, d);  // no lane looked anything up
+  if (planes_pending && alive) hp = nearest_plane<true>(sv, o, d);  // no lane looked anything up
   SphereHit sh;
   {
     const unsigned long long res = best[lane];
@@ -1171,11 +1207,14 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     else if (far) lin = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
     if (far) sh = lin;
   }
-  if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
-    const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
-    if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
-  }
   const Hit merged = alive ? ((LEAN && RT_LAZY_OBJ) ? merge_sphere_hit_lazy(sv, hp, sh) : merge_sphere_hit(sv, hp, sh)) : miss;
+  if (!LEAN && fp.cull_check && alive) {
+    // self-check frame: the linear scan must lead to the same hit.  (The sphere results themselves may differ: a plane hit inside
+    // the reach ends the rounds, and spheres farther than that plane are then never tested — they could not win.)
+    const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
+    const Hit want = merge_sphere_hit(sv, hp, full);
+    if (want.t != merged.t || want.obj != merged.obj || want.slot != merged.slot || want.plane != merged.plane) atomicAdd(&fp.counters[3], 1ull);
+  }
   RT_PHL_WAIT
   RT_PHL(5)
   return merged;
@@ -1312,7 +1351,7 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
         if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
       }
       RT_REQUEST_X2
-      alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit(sv, sh, s.o, s.d), x1, x2, seed1);
+      alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, finish_hit<MODE == 2>(sv, sh, s.o, s.d), x1, x2, seed1);
     }
     RT_PH_MARK(0)
   } else if (GRID) {
@@ -1344,7 +1383,7 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
     RT_REQUEST_X2
     if (alive) alive = path_shade<DEFER_SKY, LEAN>(sv, fp, s, h, x1, x2, seed1);
     RT_PH_MARK(3)
-  } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
+  } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && sv.dm->lists == 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
     // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
     Hit miss;
     miss.t = 0.0f;
@@ -1407,14 +1446,14 @@ __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FramePa
         const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, s.o, s.d);
         if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
       }
-      h = finish_hit(sv, sh, s.o, s.d);
+      h = finish_hit<LISTS>(sv, sh, s.o, s.d);
     }
     RT_PH_MARK(0)
   } else if (LISTS) {
     // secondary rays of a large scene: candidate lists, in rounds (rt_dirmask.h)
     h = intersect_listed<LEAN>(sv, fp, s.o, s.d, alive, h, scratch RT_PH_ARGS);
     RT_PH_MARK(1)
-  } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
+  } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && sv.dm->lists == 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
     // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
     h = intersect_masked<LEAN>(sv, fp, s.o, s.d, alive, entry, h, scratch);
     RT_PH_MARK(1)
@@ -1615,7 +1654,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   float4 *xchg = lds_all + (LISTS ? 0u : sc.image_records);  // kXchgPaths paths x 4 float4, behind the staged scene image
   // the waves' scratch for the balanced direction-mask scan (shares the exchange buffer's LDS when NW == 2: kScratchInXchg);
   // wave w's part starts w * kScanScratchBytes (kListScratchBytes) in
-  unsigned char *scratch = reinterpret_cast<unsigned char *>(xchg) + (kScratchInXchg ? 0u : kXchgBytes);
+  unsigned char *scratch = reinterpret_cast<unsigned char *>(xchg) + (scratch_in_xchg(NW) ? 0u : xchg_bytes(NW));
   if (!LISTS)
     for (uint32_t i = threadIdx.x; i < sc.image_records; i += NW * 64) lds_all[i] = sc.image[i];
   const SceneView sv = LISTS ? make_view(sc, sc.image, sc.image) : make_view(sc, lds_all, lds_all);
@@ -1718,7 +1757,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
       break;
     }
     const uint32_t need = (total + 63u) >> 6;
-    if (need < live_waves && total <= kXchgPaths) {
+    if (need < live_waves && total <= xchg_paths(NW)) {
       // pack: path number = paths in lower waves + live lanes below this one; the hit travels with the path
       if (alive) {
         const uint32_t r = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
@@ -1800,7 +1839,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
     }
     if (total == 0u) break;
     const uint32_t need = (total + 63u) >> 6;
-    if (need < live_waves && total <= kXchgPaths) {
+    if (need < live_waves && total <= xchg_paths(NW)) {
       // pack: path number = paths in lower waves + live lanes below this one
       if (alive) {
         const uint32_t r = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
@@ -2101,6 +2140,11 @@ __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, Fr
   bool alive = false;     // the lane carries a path whose hit `h` is to be shaded
   bool finished = false;  // the lane holds the result of a path that has ended (written out before the lane is re-used)
   bool work_left = true;
+  // large scenes (the kernel waits on memory): a surviving path's first random() texel is requested right after its scan, a whole
+  // refill ahead of the shading that uses it
+  constexpr bool EARLY_X = LISTS && RT_LIST_EARLY_X;
+  float x1_early = 0.0f;
+  bool has_x1 = false;
   uint32_t seg_total = 0, rough_total = 0, wave_iters = 0;
   RT_PH_DECL
   for (;;) {
@@ -2158,6 +2202,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, Fr
           h.obj = __float_as_int(g.z);
           h.plane = (__float_as_uint(g.w) & 1u) != 0u;
           alive = true;
+          has_x1 = false;
         }
         q_pos += taken;
         need = __builtin_amdgcn_ballot_w64(needy && below >= taken);
@@ -2175,7 +2220,8 @@ __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, Fr
     wave_iters += 1u;
     __builtin_amdgcn_s_setprio(0);  // issue priority by phase, as in render_blocks: the shading below everything else
     if (alive) {  // shade the pending hit (render_blocks' shading step)
-      const float x1 = fp.rnd[rng_texel(fp, s.rng)];
+      float x1 = x1_early;
+      if (!EARLY_X || !has_x1) x1 = fp.rnd[rng_texel(fp, s.rng)];
       alive = path_shade<RT_DEFER_SKY_BLOCKS, true>(sv, fp, s, h, x1, 0.0f, 0.0f);
       rough_total += s.rough & 0x7fffffffu;
       s.rough &= 0x80000000u;
@@ -2188,6 +2234,10 @@ __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, Fr
       (void)path_shade<RT_DEFER_SKY_BLOCKS, true>(sv, fp, s, h, 0.0f, 0.0f, 0.0f);
       alive = false;
       finished = true;
+    }
+    if (EARLY_X) {
+      has_x1 = alive;
+      if (alive) x1_early = fp.rnd[rng_texel(fp, s.rng)];
     }
     RT_PH_MARK(6)
   }
@@ -2647,8 +2697,9 @@ int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfi
   // bounce count and 26 bits of pixel index; the default re-packing shape carries both in full
   if ((variant == 4 || (variant == 3 && !RT_PACK_HITS)) && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26)))
     variant = variant == 4 && RT_PACK_HITS ? 3 : 0;
-  // the streamed and resident-wave shapes have no candidate-list form
+  // the streamed and resident-wave shapes have no candidate-list form, nor have the tiles that read everything from memory
   if ((variant == 2 || variant == 4) && sc.dm.lists) variant = 3;
+  if (variant == 1 && sc.dm.lists) variant = 0;
   // the re-packing, streamed and resident-wave shapes keep the whole scene image in LDS; bigger scenes render as tiles (the re-packing
   // shape of a scene with candidate lists stages nothing)
   if ((variant == 3 || variant == 2 || variant == 4) && !image_fits && !sc.dm.lists) variant = 0;
@@ -2669,6 +2720,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   const size_t lds_image = static_cast<size_t>(sc.image_records) * sizeof(float4);
   const bool image_fits = sc.image_records <= kImageLdsRecords;
   int variant = pick_variant(sc, fp, lc);
+  const bool dry = (lc.flags & 16) != 0;
   if (variant == 4 && fp.queue == nullptr) variant = 3;  // no queue handed in: the re-packing shape serves
   if (variant_used) *variant_used = variant;
   if (stage_used) *stage_used = 2;  // the re-packing and resident-wave shapes stage the whole image
@@ -2689,22 +2741,24 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     hipLaunchKernelGGL((bounce_stream<RT_STREAM_NW2, RT_STREAM_WAVES>), dim3(blocks2), dim3(RT_STREAM_NW2 * 64), lds_image, stream, sc,
                        fp, static_cast<uint32_t>(lc.refill_min), chunk);
   } else if (variant == 3) {
-    const dim3 blocks((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW, tiles_y, fp.batch);  // x: tile columns, y: tile rows, z: frames
+    // (RT_OPT_FLAGS bit 4, "dry" launches: one workgroup per kernel — all of a launch's host work, next to none of its rendering)
     const bool lists = sc.dm.enabled && sc.dm.lists;
+    const uint32_t nw = lists ? RT_BLOCK_NW_LISTS : RT_BLOCK_NW;
+    const dim3 blocks = dry ? dim3(1, 1, 1) : dim3((tiles_x + nw - 1) / nw, tiles_y, fp.batch);  // x: tile columns, y: tile rows, z: frames
     // the staged scene image + exchange buffer and the waves' scan scratch; with candidate lists nothing is staged
     const size_t bytes = lists ? kBlocksLdsExtraLists : lds_image + kBlocksLdsExtra;
     const size_t tail_bytes = lists ? RT_TAIL_NW * kListScratchBytes : lds_image + RT_TAIL_NW * kScanScratchBytes;
     const bool lean = sample_only(fp);
     const bool spill = lean && fp.spill_max != 0u && fp.queue != nullptr;
-    const dim3 threads(RT_BLOCK_NW * 64);
+    const dim3 threads(nw * 64);
 #define RT_LAUNCH_BLOCKS(WAVES, LEAN_, SPILL_)                                                                                            \
   do {                                                                                                                                    \
-    if (lists) hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, WAVES, LEAN_, SPILL_, true>), blocks, threads, bytes, stream, sc, fp);       \
+    if (lists) hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW_LISTS, WAVES, LEAN_, SPILL_, true>), blocks, threads, bytes, stream, sc, fp); \
     else hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, WAVES, LEAN_, SPILL_, false>), blocks, threads, bytes, stream, sc, fp);           \
   } while (0)
     if (fp.batch > 1u && lean) {
       if (lists) {
-        if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_LISTS;
+        if (stage_used) *stage_used = 10 * RT_BLOCK_NW_LISTS + RT_BLOCKS_WAVES_LISTS;
         if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_LISTS, true, true);
         else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_LISTS, true, false);
       } else if (sc.dm.enabled && sc.dm.words > 1u) {
@@ -2717,18 +2771,18 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
         else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH, true, false);
       }
     } else if (lean) {
-      if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_SINGLE;
+      if (stage_used) *stage_used = 10 * static_cast<int>(nw) + RT_BLOCKS_WAVES_SINGLE;
       if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_SINGLE, true, true);
       else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_SINGLE, true, false);
     } else {
-      if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_FULL;
+      if (stage_used) *stage_used = 10 * static_cast<int>(nw) + RT_BLOCKS_WAVES_FULL;
       RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_FULL, false, false);
     }
 #undef RT_LAUNCH_BLOCKS
     if (spill) {  // the spilled paths' remaining bounces, in full waves
       if (stage_used) *stage_used += 100;
       if (lc.tail_start != nullptr) (void)hipEventRecord(lc.tail_start, stream);
-      const uint32_t blocks2 = static_cast<uint32_t>(lc.tail_blocks < 1 ? 1 : lc.tail_blocks);
+      const uint32_t blocks2 = dry ? 1u : static_cast<uint32_t>(lc.tail_blocks < 1 ? 1 : lc.tail_blocks);
       const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
       if (lists)
         hipLaunchKernelGGL((tail_stream<RT_TAIL_NW, RT_TAIL_WAVES_LISTS, true>), dim3(blocks2), dim3(RT_TAIL_NW * 64), tail_bytes, stream, sc, fp,
@@ -2738,7 +2792,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
                            static_cast<uint32_t>(lc.refill_min), chunk);
     }
   } else {
-    const dim3 blocks((tiles_x + (kTileBlock / 64) - 1) / (kTileBlock / 64), tiles_y, fp.batch);
+    const dim3 blocks = dry ? dim3(1, 1, 1) : dim3((tiles_x + (kTileBlock / 64) - 1) / (kTileBlock / 64), tiles_y, fp.batch);
     const bool lists = sc.dm.enabled && sc.dm.lists;
     if (stage_used) *stage_used = variant == 1 ? 0 : (lists ? 4 : ((sc.grid.enabled && !(lc.flags & 2)) ? 3 : (image_fits ? 2 : 1)));
     if (variant == 1) {
@@ -2749,7 +2803,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
       const size_t bytes = lds_sph + (static_cast<size_t>(sc.grid.off_items - sc.grid.off_cells) +
                                       (static_cast<size_t>(sc.grid.n_items) * 2 + 15) / 16) * sizeof(float4);
       if (bytes <= 12u * 1024u) {
-        hipLaunchKernelGGL((render_tiles<3, 128>), dim3((tiles_x + 1) / 2, tiles_y, fp.batch), dim3(128), bytes, stream, sc, fp);
+        hipLaunchKernelGGL((render_tiles<3, 128>), dry ? dim3(1, 1, 1) : dim3((tiles_x + 1) / 2, tiles_y, fp.batch), dim3(128), bytes, stream, sc, fp);
       } else {
         hipLaunchKernelGGL((render_tiles<3, kTileBlock>), blocks, dim3(kTileBlock), bytes, stream, sc, fp);
       }
@@ -2762,16 +2816,16 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   return static_cast<int>(hipGetLastError());
 }
 
-int launch_resolve(const ResolveParams &rp, hipStream_t stream) {
+int launch_resolve(const ResolveParams &rp, hipStream_t stream, bool dry) {
   if (rp.pixels == 0 || rp.batch == 0) return 0;
-  hipLaunchKernelGGL(resolve_batch_kernel, dim3((rp.pixels + 255u) / 256u), dim3(256), 0, stream, rp);
+  hipLaunchKernelGGL(resolve_batch_kernel, dim3(dry ? 1u : (rp.pixels + 255u) / 256u), dim3(256), 0, stream, rp);
   return static_cast<int>(hipGetLastError());
 }
 
-int launch_assemble(const AssembleParams &ap, hipStream_t stream) {
+int launch_assemble(const AssembleParams &ap, hipStream_t stream, bool dry) {
   const uint64_t n = static_cast<uint64_t>(ap.width) * ap.height;
   if (n == 0) return 0;
-  hipLaunchKernelGGL(assemble_strips_kernel, dim3(static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, stream, ap);
+  hipLaunchKernelGGL(assemble_strips_kernel, dim3(dry ? 1u : static_cast<uint32_t>((n + 255u) / 256u)), dim3(256), 0, stream, ap);
   return static_cast<int>(hipGetLastError());
 }
 
@@ -2809,9 +2863,10 @@ uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const Lau
   // small launches do not earn back (RT_OPT_FLAGS bit 2 lifts the size rule: tests)
   if (fp.reflection_limit < 2u || (launch_tiles(fp) < kTailMinTiles && !(lc.flags & 4))) return 0u;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile, tiles_y = (fp.local_rows + kTile - 1) / kTile;
-  const uint64_t blocks = static_cast<uint64_t>((tiles_x + RT_BLOCK_NW - 1) / RT_BLOCK_NW) * tiles_y * fp.batch;  // render_blocks' grid
+  const uint32_t nw = (sc.dm.enabled && sc.dm.lists) ? RT_BLOCK_NW_LISTS : RT_BLOCK_NW;
+  const uint64_t blocks = static_cast<uint64_t>((tiles_x + nw - 1) / nw) * tiles_y * fp.batch;  // render_blocks' grid
   const uint64_t per_shard = (blocks + kQueueShards - 1) / kQueueShards;  // workgroups that append to one shard, each once
-  uint64_t t = wanted > RT_BLOCK_NW * 64u ? RT_BLOCK_NW * 64u : wanted;
+  uint64_t t = wanted > nw * 64u ? nw * 64u : wanted;
   const uint64_t fit = kTailQueueBudget / (per_shard * kQueueShards * 5ull * sizeof(float4));
   if (t > fit) t = fit;
   if (t < 4u || per_shard * t > 0xffffffffull) return 0u;

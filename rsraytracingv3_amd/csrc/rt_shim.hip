@@ -6,7 +6,9 @@
 // with the same specified float32 functions the device uses, and launches the render kernel.
 // No CPU rendering fallback exists here by design.
 #include <hip/hip_runtime.h>
+#include <roctracer/roctx.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -87,7 +89,8 @@ struct rt_context {
   int blocks_per_cu = 0;    // RT_OPT_BLOCKS_PER_CU (0 = occupancy query)
   int cu_count = 0;
   int tile_chunk = 2;       // RT_OPT_TILE_CHUNK
-  int tail_spill = kDefaultTailSpill;  // RT_OPT_TAIL_SPILL: a workgroup with at most this many paths left hands them to tail_stream
+  int tail_spill = -1;      // RT_OPT_TAIL_SPILL: a workgroup with at most this many paths left hands them to tail_stream; -1 = the default of
+                            // the scene's kind (kDefaultTailSpill, kDefaultTailSpillLists)
   int tail_spill_single = kDefaultTailSpillSingle;  // RT_OPT_TAIL_SPILL_SINGLE: the same for single-frame launches in flight
   int tail_occupancy_blocks = 0;       // resident tail_stream workgroups per CU for tail_occupancy_records of scene image
   uint32_t tail_occupancy_records = 0;
@@ -194,6 +197,15 @@ struct rt_context {
 
 namespace {
 
+// A named range around a phase of the shim, visible in rocprofv3 --marker-trace timelines next to the kernels it launches
+// (a call into libroctx64 that does nothing while no profiler listens).
+struct Range {
+  explicit Range(const char *name) { (void)roctxRangePushA(name); }
+  ~Range() { (void)roctxRangePop(); }
+  Range(const Range &) = delete;
+  Range &operator=(const Range &) = delete;
+};
+
 int fail(rt_context *ctx, int code, const char *fmt, ...) {
   if (ctx) {
     char buf[512];
@@ -293,6 +305,15 @@ int alloc_target(rt_context *ctx) {
   if (ctx->present_stream) RT_HIP(ctx, hipStreamSynchronize(ctx->present_stream));  // a presentation copy may still read the old target
   ctx->present_guard = -1;
   free_target(ctx);
+  // the path queues were sized for the old target's launches (a 4K or 64-frame launch may hold gigabytes): the next launch that
+  // spills allocates what it needs
+  for (hipStream_t rs : ctx->render_stream)
+    if (rs) (void)hipStreamSynchronize(rs);
+  for (int i = 0; i <= rt_context::kMaxInflight; ++i) {
+    (void)hipFree(ctx->d_queue[i]);
+    ctx->d_queue[i] = nullptr;
+    ctx->queue_cap[i] = 0;
+  }
   ctx->local_rows = count_local_rows(ctx->height, ctx->rank, ctx->world, ctx->strip_rows);
   ctx->masks_dirty = true;
   ctx->kept_frames = 0;
@@ -419,6 +440,7 @@ int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
 // table: the caller then builds the sphere grid).  The caller has synchronised the context's stream.
 constexpr size_t kDirListMaxBytes = 768ull << 20;
 int build_dirlist(rt_context *ctx, const float4 *sph, uint32_t n) {
+  const Range range("rt355 candidate lists");
   std::vector<float4> reg(n);
   uint32_t target = static_cast<uint32_t>(ctx->dirlist_cells);
   uint32_t reach = static_cast<uint32_t>(ctx->dirlist_reach);
@@ -491,7 +513,7 @@ constexpr int kCommPatienceMs = 20000;  // how long leaving a communicator waits
 
 extern "C" {
 
-static void release_comm(rt_context *ctx, int patience_ms);
+static void release_comm(rt_context *ctx, int patience_ms, bool always_abort = false);
 
 uint32_t rt_abi_version(void) { return RT355_ABI_VERSION; }
 
@@ -728,6 +750,7 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
                  uint32_t light_count, const void *config112) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
   if (!config112 || (!objects && object_count)) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_set_scene: NULL blob");
+  const Range range("rt355 rt_set_scene");
   (void)lights;       // uploaded by the reference (connection.rs:379) but never read by the
   (void)light_count;  // shader (inputs.hlsl:67 has no use) — accepted and ignored
   RT_HIP(ctx, hipSetDevice(ctx->device));
@@ -859,303 +882,9 @@ int rt_set_partition(rt_context *ctx, uint32_t rank, uint32_t world, uint32_t st
   return (ctx->width && ctx->height) ? alloc_target(ctx) : RT_OK;
 }
 
-int rt_grid_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t min_spheres, rt_grid_info *info, uint32_t *cell_start,
-                       uint32_t cell_cap, uint16_t *items, uint32_t item_cap) {
-  if (!info || (!spheres_xyzr2 && n_spheres)) return RT_ERR_INVALID_ARGUMENT;
-  try {
-    const size_t n_pad = (static_cast<size_t>(n_spheres) + kSphBatch - 1) / kSphBatch * kSphBatch + kSphBatch;
-    std::vector<float4> sph(n_pad, make_float4(0.0f, 0.0f, 0.0f, -INFINITY));
-    for (uint32_t i = 0; i < n_spheres; ++i)
-      sph[i] = make_float4(spheres_xyzr2[4 * i], spheres_xyzr2[4 * i + 1], spheres_xyzr2[4 * i + 2], spheres_xyzr2[4 * i + 3]);
-    const GridBuild g = build_grid(sph, n_spheres, n_pad, min_spheres);
-    std::memset(info, 0, sizeof *info);
-    info->enabled = g.params.enabled;
-    if (!g.params.enabled) return RT_OK;
-    info->nx = g.params.nx;
-    info->ny = g.params.ny;
-    info->nz = g.params.nz;
-    info->n_cells = g.params.n_cells;
-    info->n_items = g.params.n_items;
-    for (int a = 0; a < 3; ++a) {
-      info->gmin[a] = g.params.gmin[a];
-      info->gmax[a] = g.params.gmax[a];
-      info->cell[a] = g.params.cell[a];
-      info->inv_cell[a] = g.params.inv_cell[a];
-      info->near_min[a] = g.params.near_min[a];
-      info->near_max[a] = g.params.near_max[a];
-    }
-    info->t_margin = g.params.t_margin;
-    if (cell_start && cell_cap >= g.cell_start.size()) std::memcpy(cell_start, g.cell_start.data(), g.cell_start.size() * 4);
-    if (items && item_cap >= g.items.size()) std::memcpy(items, g.items.data(), g.items.size() * 2);
-    return RT_OK;
-  } catch (...) {
-    return RT_ERR_OUT_OF_MEMORY;
-  }
-}
-
-// Host-side twin of the direction-mask table (rt_dirmask.h), for inspection and for testing its sets without a GPU.
-static DirMaskParams dirmask_from_info(const rt_dirmask_info *info) {
-  DirMaskParams dm{};
-  dm.enabled = info->enabled;
-  dm.nx = info->nx;
-  dm.ny = info->ny;
-  dm.nz = info->nz;
-  dm.k = info->k;
-  dm.bins = info->bins;
-  dm.words = info->words;
-  dm.entries = info->nx * info->ny * info->nz * info->bins;
-  dm.half_k = 0.5f * static_cast<float>(info->k);
-  for (int a = 0; a < 3; ++a) {
-    dm.bmin[a] = info->bmin[a];
-    dm.bmax[a] = info->bmax[a];
-    dm.cell[a] = info->cell[a];
-    dm.inv_cell[a] = info->inv_cell[a];
-    dm.near_min[a] = info->near_min[a];
-    dm.near_max[a] = info->near_max[a];
-  }
-  return dm;
-}
-
-int rt_dirmask_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t target_cells, uint32_t k, rt_dirmask_info *info,
-                          uint64_t *table, size_t table_cap) {
-  if (!info || (!spheres_xyzr2 && n_spheres)) return RT_ERR_INVALID_ARGUMENT;
-  std::memset(info, 0, sizeof *info);
-  if (n_spheres == 0 || n_spheres > kDirMaskMaxSpheres) return RT_OK;  // not served: info->enabled stays 0
-  float4 sph[kDirMaskMaxSpheres], reg[kDirMaskMaxSpheres];
-  for (uint32_t i = 0; i < n_spheres; ++i)
-    sph[i] = make_float4(spheres_xyzr2[4 * i], spheres_xyzr2[4 * i + 1], spheres_xyzr2[4 * i + 2], spheres_xyzr2[4 * i + 3]);
-  const DirMaskParams dm = dirmask_plan(sph, n_spheres, target_cells, k, reg);
-  if (!dm.enabled) return RT_OK;
-  info->enabled = 1;
-  info->nx = dm.nx;
-  info->ny = dm.ny;
-  info->nz = dm.nz;
-  info->k = dm.k;
-  info->bins = dm.bins;
-  info->words = dm.words;
-  for (int a = 0; a < 3; ++a) {
-    info->bmin[a] = dm.bmin[a];
-    info->bmax[a] = dm.bmax[a];
-    info->cell[a] = dm.cell[a];
-    info->inv_cell[a] = dm.inv_cell[a];
-    info->near_min[a] = dm.near_min[a];
-    info->near_max[a] = dm.near_max[a];
-  }
-  const size_t entries = static_cast<size_t>(dm.nx) * dm.ny * dm.nz * dm.bins;
-  if (table && table_cap >= entries * dm.words)
-    for (size_t e = 0; e < entries; ++e) {
-      unsigned long long w[2];
-      dirmask_entry(dm, static_cast<uint32_t>(e / dm.bins), static_cast<uint32_t>(e % dm.bins), reg, n_spheres, w);
-      table[e * dm.words] = w[0];
-      if (dm.words > 1u) table[e * dm.words + 1u] = w[1];
-    }
-  return RT_OK;
-}
-
-int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, const float *origin3, const float *direction3,
-                           uint64_t *mask2, int *served) {
-  if (!info || !table || !origin3 || !direction3 || !mask2 || !served || !info->enabled) return RT_ERR_INVALID_ARGUMENT;
-  const DirMaskParams dm = dirmask_from_info(info);
-  const f3 o = mk3(origin3[0], origin3[1], origin3[2]), d = mk3(direction3[0], direction3[1], direction3[2]);
-  mask2[0] = mask2[1] = 0;
-  *served = 0;
-  // the lane's arithmetic (dirmask_lookup in rt_kernels.hip), with an IEEE reciprocal where the device uses v_rcp_f32
-  const bool ok = (fabsf(dot3(d, d) - 1.0f) <= 4e-6f) && (o.x >= dm.near_min[0]) && (o.x <= dm.near_max[0]) && (o.y >= dm.near_min[1]) &&
-                  (o.y <= dm.near_max[1]) && (o.z >= dm.near_min[2]) && (o.z <= dm.near_max[2]);
-  if (!ok) return RT_OK;
-  *served = 1;
-  f3 p = o;
-  const bool outside = !((o.x >= dm.bmin[0]) && (o.x <= dm.bmax[0]) && (o.y >= dm.bmin[1]) && (o.y <= dm.bmax[1]) && (o.z >= dm.bmin[2]) &&
-                         (o.z <= dm.bmax[2]));
-  if (outside) {
-    const float big = 1e30f;
-    const float ivx = fabsf(d.x) > 1e-30f ? 1.0f / d.x : (d.x < 0.0f ? -big : big);
-    const float ivy = fabsf(d.y) > 1e-30f ? 1.0f / d.y : (d.y < 0.0f ? -big : big);
-    const float ivz = fabsf(d.z) > 1e-30f ? 1.0f / d.z : (d.z < 0.0f ? -big : big);
-    const float ax = (dm.bmin[0] - o.x) * ivx, bx = (dm.bmax[0] - o.x) * ivx;
-    const float ay = (dm.bmin[1] - o.y) * ivy, by = (dm.bmax[1] - o.y) * ivy;
-    const float az = (dm.bmin[2] - o.z) * ivz, bz = (dm.bmax[2] - o.z) * ivz;
-    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    if (!(t_in <= t_out)) return RT_OK;  // misses the box: the empty set
-    p = fma3(d, t_in, o);
-  }
-  const uint32_t cell = dirmask_cell(dm, p);
-  const float inv_major = 1.0f / fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-  const size_t entry = static_cast<size_t>(cell) * dm.bins + dirmask_bin(d, inv_major, dm.k, dm.half_k);
-  mask2[0] = table[entry * dm.words];
-  if (dm.words > 1u) mask2[1] = table[entry * dm.words + 1u];
-  return RT_OK;
-}
-
-// Host-side twin of the candidate lists (rt_dirmask.h "Candidate lists"), for testing them without a GPU: the plan, single
-// entries on demand (a whole table is hundreds of megabytes), and a lane's walk through its rounds.
-static DirMaskParams dirlist_from_info(const rt_dirlist_info *info) {
-  DirMaskParams dm{};
-  dm.enabled = info->enabled;
-  dm.nx = info->nx;
-  dm.ny = info->ny;
-  dm.nz = info->nz;
-  dm.k = info->k;
-  dm.bins = info->bins;
-  dm.words = kDirListWords;
-  dm.entries = info->nx * info->ny * info->nz * info->bins;
-  dm.half_k = 0.5f * static_cast<float>(info->k);
-  dm.lists = 1;
-  dm.reach_unit = info->reach_unit;
-  dm.s_cap = info->s_cap;
-  for (int a = 0; a < 3; ++a) {
-    dm.bmin[a] = info->bmin[a];
-    dm.bmax[a] = info->bmax[a];
-    dm.cell[a] = info->cell[a];
-    dm.inv_cell[a] = info->inv_cell[a];
-  }
-  return dm;
-}
-
-int rt_dirlist_plan_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t target_cells, uint32_t k, uint32_t reach_cells,
-                         rt_dirlist_info *info, float *registered_xyzr) {
-  if (!info || (!spheres_xyzr2 && n_spheres)) return RT_ERR_INVALID_ARGUMENT;
-  std::memset(info, 0, sizeof *info);
-  try {
-    std::vector<float4> sph(n_spheres), reg(n_spheres);
-    for (uint32_t i = 0; i < n_spheres; ++i)
-      sph[i] = make_float4(spheres_xyzr2[4 * i], spheres_xyzr2[4 * i + 1], spheres_xyzr2[4 * i + 2], spheres_xyzr2[4 * i + 3]);
-    const DirMaskParams dm = dirlist_plan(sph.data(), n_spheres, target_cells, k, reach_cells, reg.data());
-    if (!dm.enabled) return RT_OK;
-    info->enabled = 1;
-    info->nx = dm.nx;
-    info->ny = dm.ny;
-    info->nz = dm.nz;
-    info->k = dm.k;
-    info->bins = dm.bins;
-    info->reach_unit = dm.reach_unit;
-    info->s_cap = dm.s_cap;
-    for (int a = 0; a < 3; ++a) {
-      info->bmin[a] = dm.bmin[a];
-      info->bmax[a] = dm.bmax[a];
-      info->cell[a] = dm.cell[a];
-      info->inv_cell[a] = dm.inv_cell[a];
-    }
-    if (registered_xyzr) std::memcpy(registered_xyzr, reg.data(), static_cast<size_t>(n_spheres) * sizeof(float4));
-    return RT_OK;
-  } catch (...) {
-    return RT_ERR_OUT_OF_MEMORY;
-  }
-}
-
-int rt_dirlist_entry_host(const rt_dirlist_info *info, const float *registered_xyzr, uint32_t n_spheres, uint32_t cell, uint32_t bin,
-                          uint32_t *entry8) {
-  if (!info || !info->enabled || !registered_xyzr || !entry8 || cell >= info->nx * info->ny * info->nz || bin >= info->bins)
-    return RT_ERR_INVALID_ARGUMENT;
-  const DirMaskParams dm = dirlist_from_info(info);
-  dirlist_entry(dm, cell, bin, reinterpret_cast<const float4 *>(registered_xyzr), nullptr, n_spheres, entry8);
-  return RT_OK;
-}
-
-// One ray through the rounds of intersect_listed (rt_kernels.hip), with IEEE reciprocals where the device uses v_rcp_f32 and
-// entries computed on demand: *listed_key / *listed_slot = what the rounds find (slot -1: nothing; *far = 1: the ray is not
-// served and the kernel scans linearly — then they are the linear result), *linear_key / *linear_slot = the linear scan of
-// all spheres with the same arithmetic; `t_plane`: the distance of the ray's plane hit (a large value for none), which ends the
-// rounds like a sphere hit does.  The two results must be equal for every ray.
-int rt_dirlist_walk_host(const rt_dirlist_info *info, const float *spheres_xyzr2, const float *registered_xyzr, uint32_t n_spheres,
-                         const float *origin3, const float *direction3, float t_plane, uint32_t *listed_key, int32_t *listed_slot,
-                         uint32_t *linear_key, int32_t *linear_slot, uint32_t *rounds, uint32_t *tests, int *far) {
-  if (!info || !info->enabled || !spheres_xyzr2 || !registered_xyzr || !origin3 || !direction3 || !listed_key || !listed_slot ||
-      !linear_key || !linear_slot || !rounds || !tests || !far)
-    return RT_ERR_INVALID_ARGUMENT;
-  constexpr uint32_t kEps = 0x358637bdu, kNone = 0x49742400u - kEps;  // as in rt_kernels.hip
-  const DirMaskParams dm = dirlist_from_info(info);
-  const f3 o = mk3(origin3[0], origin3[1], origin3[2]), d = mk3(direction3[0], direction3[1], direction3[2]);
-  auto test = [&](uint32_t i, uint32_t &key, int32_t &slot) {  // one sphere of ray.hlsl:53-68, the kernels' arithmetic
-    const float *g = spheres_xyzr2 + 4 * static_cast<size_t>(i);
-    const float nx = o.x - g[0], ny = o.y - g[1], nz = o.z - g[2];
-    const float dn = fmaf(d.z, nz, fmaf(d.y, ny, d.x * nx));
-    const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g[3]));
-    if (fminf(q, -dn) >= 0.0f) {
-      const uint32_t k = f2u(-dn - sqrtf(q)) - kEps;
-      if (k < key || (k == key && k < kNone && static_cast<int32_t>(i) < slot)) {
-        if (k < kNone) {
-          key = k;
-          slot = static_cast<int32_t>(i);
-        }
-      }
-    }
-  };
-  *linear_key = kNone;
-  *linear_slot = -1;
-  for (uint32_t i = 0; i < n_spheres; ++i) test(i, *linear_key, *linear_slot);
-  *listed_key = kNone;
-  *listed_slot = -1;
-  *rounds = 0;
-  *tests = 0;
-  *far = 0;
-  const bool unit = fabsf(dot3(d, d) - 1.0f) <= 4e-6f;
-  const bool inside = (o.x >= dm.bmin[0]) && (o.x <= dm.bmax[0]) && (o.y >= dm.bmin[1]) && (o.y <= dm.bmax[1]) && (o.z >= dm.bmin[2]) &&
-                      (o.z <= dm.bmax[2]);
-  bool todo = unit, is_far = !unit;
-  float s = 0.0f;
-  if (todo && !inside) {
-    const float big = 1e30f;
-    const float ivx = fabsf(d.x) > 1e-30f ? 1.0f / d.x : (d.x < 0.0f ? -big : big);
-    const float ivy = fabsf(d.y) > 1e-30f ? 1.0f / d.y : (d.y < 0.0f ? -big : big);
-    const float ivz = fabsf(d.z) > 1e-30f ? 1.0f / d.z : (d.z < 0.0f ? -big : big);
-    const float ax = (dm.bmin[0] - o.x) * ivx, bx = (dm.bmax[0] - o.x) * ivx;
-    const float ay = (dm.bmin[1] - o.y) * ivy, by = (dm.bmax[1] - o.y) * ivy;
-    const float az = (dm.bmin[2] - o.z) * ivz, bz = (dm.bmax[2] - o.z) * ivz;
-    const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    const bool finite = (o.x == o.x) && (o.y == o.y) && (o.z == o.z);
-    const bool misses = finite && !(t_in <= t_out);
-    const bool beyond = !finite || (t_in > dm.s_cap);
-    s = t_in;
-    is_far = beyond;
-    todo = !misses && !beyond;
-  }
-  const float inv_major = 1.0f / fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
-  const uint32_t bin = unit ? dirmask_bin(d, inv_major, dm.k, dm.half_k) : 0u;
-  while (todo) {
-    if (*rounds == 48u) {
-      is_far = true;
-      break;
-    }
-    *rounds += 1;
-    const f3 p = fma3(d, s, o);
-    uint32_t e[8];
-    dirlist_entry(dm, dirmask_cell(dm, p), bin, reinterpret_cast<const float4 *>(registered_xyzr), nullptr, n_spheres, e);
-    const uint32_t n = (e[0] >> 12) & 15u, q = e[0] & 0xfffu;
-    for (uint32_t j = 0; j < n; ++j) {
-      const uint32_t hw = 1u + j;
-      test((e[hw >> 1] >> (16u * (hw & 1u))) & 0xffffu, *listed_key, *listed_slot);
-      *tests += 1;
-    }
-    const float t_sphere = u2f(*listed_key + kEps);
-    const float t_near = fminf(t_plane, t_sphere);
-    const float reach = static_cast<float>(q) * dm.reach_unit;
-    if (q == 0u) {
-      is_far = true;
-      todo = false;
-    } else if (t_near <= fmaf(reach, kDirListDone, s)) {
-      todo = false;
-    } else {
-      s = fmaf(reach, kDirListStep, s);
-      const f3 pn = fma3(d, s, o);
-      const bool in_box = (pn.x >= dm.bmin[0]) && (pn.x <= dm.bmax[0]) && (pn.y >= dm.bmin[1]) && (pn.y <= dm.bmax[1]) &&
-                          (pn.z >= dm.bmin[2]) && (pn.z <= dm.bmax[2]);
-      if (!in_box) todo = false;
-      else if (s > dm.s_cap) {
-        is_far = true;
-        todo = false;
-      }
-    }
-  }
-  if (is_far) {
-    *far = 1;
-    *listed_key = *linear_key;
-    *listed_slot = *linear_slot;
-  }
-  return RT_OK;
-}
+// (the host-side twins of the scene structures — rt_grid_build_host, rt_dirmask_*_host, rt_dirlist_*_host — live in
+// rt_host_twins.h: plain host code, also built on its own with the address and undefined-behaviour sanitizers, `make host-asan`)
+#include "rt_host_twins.h"
 
 int rt_comm_available(char *why_buf, size_t why_cap) {
   std::string why;
@@ -1220,7 +949,9 @@ int rt_comm_init(rt_context *ctx, const void *id128, uint32_t rank, uint32_t wor
 // Leaving a communicator: waits for the exchange in flight — but only for `patience_ms`; an exchange that has not
 // completed by then (a peer that never posted its side) is given up with ncclCommAbort, after which the RCCL kernel on
 // the communication stream ends and the streams can be synchronised.  Never hangs.
-static void release_comm(rt_context *ctx, int patience_ms) {
+// always_abort (rt_comm_abort): never ncclCommDestroy — that may wait for peers that never arrived (a hand-shake that failed on
+// another rank) — whatever the streams look like.
+static void release_comm(rt_context *ctx, int patience_ms, bool always_abort) {
   if (!ctx->comm) return;
   std::string why;
   const RcclApi &api = rccl_api(&why);
@@ -1234,7 +965,7 @@ static void release_comm(rt_context *ctx, int patience_ms) {
     std::this_thread::sleep_for(std::chrono::milliseconds(2));
   }
   if (api.ok()) {
-    if (done) (void)api.CommDestroy(ctx->comm);
+    if (done && !always_abort) (void)api.CommDestroy(ctx->comm);
     else (void)api.CommAbort(ctx->comm);
   }
   ctx->comm = nullptr;
@@ -1273,7 +1004,7 @@ int rt_comm_abort(rt_context *ctx) {
   (void)hipSetDevice(ctx->device);
   // no waiting first: the point is to get rid of an exchange that does not finish (ncclCommAbort is part of the
   // required symbol set of rt_comm.h, so the synchronisation inside release_comm cannot meet a live RCCL kernel)
-  release_comm(ctx, 0);
+  release_comm(ctx, 0, true);
   ctx->comm_world = 0;
   ctx->comm_rank = 0;
   ctx->rank = 0;
@@ -1409,7 +1140,7 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       ctx->timing = value != 0;
       return RT_OK;
     case RT_OPT_TAIL_SPILL:
-      if (value < 0 || value > 128) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TAIL_SPILL takes 0..128");
+      if (value < -1 || value > 128) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_TAIL_SPILL takes -1 (default) or 0..128");
       ctx->tail_spill = value;
       return RT_OK;
     case RT_OPT_TAIL_SPILL_SINGLE:
@@ -1449,6 +1180,7 @@ int rt_selftest_sqrt(rt_context *ctx, uint64_t *mismatches) {
 // all-gather — on the communication stream, so it runs beside the next launch's rendering; rank 0 then
 // interleaves the strips into the frame.
 static int gather_frame(rt_context *ctx, int b) {
+  const Range range("rt355 gather (RCCL)");
   std::string why;
   const RcclApi &api = rccl_api(&why);
   if (!api.ok()) return fail(ctx, RT_ERR_DEVICE, "RCCL is gone: %s", why.c_str());
@@ -1473,7 +1205,7 @@ static int gather_frame(rt_context *ctx, int b) {
       ap.frame = ctx->d_frame;
       ap.own = bufs[b];
       ap.stack = ctx->d_stack;
-      if (launch_assemble(ap, ctx->comm_stream) != 0) return fail(ctx, RT_ERR_DEVICE, "assemble launch failed");
+      if (launch_assemble(ap, ctx->comm_stream, (ctx->flags & 16) != 0) != 0) return fail(ctx, RT_ERR_DEVICE, "assemble launch failed");
     }
   }
   if (rc != ncclSuccess) return fail(ctx, RT_ERR_DEVICE, "RCCL gather failed: %s", api.GetErrorString(rc));
@@ -1485,6 +1217,7 @@ static int gather_frame(rt_context *ctx, int b) {
 // One launch of `batch` frames (1 = the plain rt_render): jitter {x, y} and progressive count per frame.
 static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, const uint32_t *counts) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  const Range range(batch > 1u ? "rt355 rt_render_frames" : "rt355 rt_render");
   if (batch < 1u || batch > kMaxBatch)
     return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_render_frames: %u frames, 1..%u allowed per call", batch, kMaxBatch);
   if (batch > 1u && (ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS)))
@@ -1720,7 +1453,8 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     lc.stream_blocks = per_cu_stream * ctx->cu_count;
   }
   fp.spill_max = 0;
-  const int spill_wanted = batch > 1u ? ctx->tail_spill : ctx->tail_spill_single;
+  const int spill_default = (ctx->scene.dm.enabled && ctx->scene.dm.lists) ? kDefaultTailSpillLists : kDefaultTailSpill;
+  const int spill_wanted = batch > 1u ? (ctx->tail_spill >= 0 ? ctx->tail_spill : spill_default) : ctx->tail_spill_single;
   if (spill_wanted > 0 && fp.queue == nullptr) {  // tail spill of the re-packing shape: needs the queue and tail_stream's grid
     uint32_t shard_cap = 0;
     const uint32_t t = tail_spill_plan(ctx->scene, fp, lc, static_cast<uint32_t>(spill_wanted), &shard_cap);
@@ -1736,9 +1470,11 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
         if (hipMalloc(&ctx->d_queue[qi], 5 * plane * sizeof(float4)) == hipSuccess) {
           ctx->queue_cap[qi] = 5 * plane;
           have = true;
+          ctx->stats.tail_spill_unavailable = 0;
         } else {
-          (void)hipGetLastError();  // no memory for the queue: the launch runs without the spill
+          (void)hipGetLastError();  // no memory for the queue: the launch runs without the spill — and says so (rt_stats.tail_spill_unavailable)
           ctx->d_queue[qi] = nullptr;
+          ctx->stats.tail_spill_unavailable = 1;
         }
       }
       if (have) {
@@ -1784,7 +1520,7 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_stop[slot], 0));
   ctx->rnd_used[rnd] = true;  // (rt_set_random records the copy's last use itself, when it is about to refill it)
   rnd_lock.unlock();
-  if (staging != nullptr && launch_resolve(rp, ctx->stream) != 0) return fail(ctx, RT_ERR_DEVICE, "resolve launch failed");
+  if (staging != nullptr && launch_resolve(rp, ctx->stream, (ctx->flags & 16) != 0) != 0) return fail(ctx, RT_ERR_DEVICE, "resolve launch failed");
   RT_HIP(ctx, hipEventRecord(ctx->ev_resolved[slot], ctx->stream));
   if (pipelined) {  // the lane's sample buffer is free again once this launch's resolve has run
     ctx->resolve_slot[lane] = slot;
@@ -1798,6 +1534,11 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   if (ctx->exchanges()) {  // (a member of an rt_multi: its owner gathers after all members have launched)
     ctx->last_send = send;
     ctx->comm_launches += 1;
+  }
+  {
+    size_t queue_records = 0;
+    for (size_t cap : ctx->queue_cap) queue_records += cap;
+    ctx->stats.path_queue_bytes = static_cast<uint64_t>(queue_records) * sizeof(float4);
   }
   ctx->stats.last_variant = static_cast<uint32_t>(variant_used);
   ctx->stats.last_stage = static_cast<uint32_t>(stage_used);
@@ -1935,6 +1676,7 @@ static int present_from(rt_context *ctx, uint32_t slot, const void *src, size_t 
 
 int rt_present_async(rt_context *ctx, uint32_t slot) {
   if (!ctx) return RT_ERR_INVALID_ARGUMENT;
+  const Range range("rt355 rt_present_async");
   if (slot >= rt_context::kPresentSlots) return fail(ctx, RT_ERR_INVALID_ARGUMENT, "rt_present_async: slot %u of %u", slot, rt_context::kPresentSlots);
   RT_HIP(ctx, hipSetDevice(ctx->device));
   if (ctx->comm) {  // a communicator's frame is assembled on rank 0, on the communication stream: the copy queues up behind the gather
@@ -2224,9 +1966,15 @@ struct rt_multi {
   std::condition_variable job_cv, done_cv;
   uint64_t job_generation = 0;
   uint32_t job_pending = 0;
+  // the same two counters for the threads that SPIN for a few tens of microseconds before they sleep on the condition variables:
+  // in a render loop the next frame's job arrives within microseconds of the last one's end, and a futex wake-up costs more than
+  // the job's own HIP calls
+  std::atomic<uint64_t> job_generation_hint{0};
+  std::atomic<uint32_t> job_pending_hint{0};
   bool quit = false;
   std::function<int(rt_context *)> job;
   std::vector<int> job_result;
+  uint32_t peers_direct = 0, peers_staged = 0;  // members on another device than the first: with / without direct peer access to it
   std::string error;
 };
 
@@ -2240,6 +1988,7 @@ static void multi_worker(rt_multi *m, uint32_t index) {
   for (;;) {
     std::function<int(rt_context *)> job;
     {
+      for (int spin = 0; spin < 4000 && m->job_generation_hint.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
       std::unique_lock<std::mutex> lock(m->job_mutex);
       m->job_cv.wait(lock, [&] { return m->quit || m->job_generation != seen; });
       if (m->quit) return;
@@ -2251,6 +2000,7 @@ static void multi_worker(rt_multi *m, uint32_t index) {
       std::lock_guard<std::mutex> lock(m->job_mutex);
       m->job_result[index] = rc;
       m->job_pending -= 1;
+      m->job_pending_hint.store(m->job_pending, std::memory_order_release);
     }
     m->done_cv.notify_one();
   }
@@ -2269,9 +2019,12 @@ static int multi_run(rt_multi *m, const char *what, const std::function<int(rt_c
     std::lock_guard<std::mutex> lock(m->job_mutex);
     m->job = fn;
     m->job_pending = static_cast<uint32_t>(m->ctx.size());
+    m->job_pending_hint.store(m->job_pending, std::memory_order_release);
     m->job_generation += 1;
+    m->job_generation_hint.store(m->job_generation, std::memory_order_release);
   }
   m->job_cv.notify_all();
+  for (int spin = 0; spin < 20000 && m->job_pending_hint.load(std::memory_order_acquire) != 0u; ++spin) __builtin_ia32_pause();
   {
     std::unique_lock<std::mutex> lock(m->job_mutex);
     m->done_cv.wait(lock, [&] { return m->job_pending == 0; });
@@ -2281,18 +2034,23 @@ static int multi_run(rt_multi *m, const char *what, const std::function<int(rt_c
   return RT_OK;
 }
 
+// what a member's own thread does after its launch: mark the frame's strips ready for the gather (one call on that thread
+// instead of two per member on the caller's)
+static int multi_mark_ready(rt_context *c) {
+  if (!c->multi_member) return RT_OK;
+  if (hipEventRecord(c->frame_ready[c->last_send], c->stream) != hipSuccess) return fail(c, RT_ERR_DEVICE, "rt_multi: recording a frame event failed");
+  return RT_OK;
+}
+
 // after every member has launched: strips -> device 0 -> frame
 static int multi_gather(rt_multi *m) {
   const uint32_t n = static_cast<uint32_t>(m->ctx.size());
   if (n == 1u) return RT_OK;  // one device: its target is the frame
+  const Range range("rt355 gather (peer copies)");
   rt_context *root = m->ctx[0];
   const int b = root->last_send;
-  for (uint32_t i = 0; i < n; ++i) {
-    rt_context *c = m->ctx[i];
-    if (c->last_send != b) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: the members' targets are out of step");
-    if (hipSetDevice(c->device) != hipSuccess || hipEventRecord(c->frame_ready[b], c->stream) != hipSuccess)
-      return multi_fail(m, RT_ERR_DEVICE, "rt_multi: recording a frame event failed");
-  }
+  for (uint32_t i = 0; i < n; ++i)
+    if (m->ctx[i]->last_send != b) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: the members' targets are out of step");
   if (hipSetDevice(m->device0) != hipSuccess) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: hipSetDevice failed");
   for (uint32_t i = 0; i < n; ++i)
     if (hipStreamWaitEvent(m->gather_stream, m->ctx[i]->frame_ready[b], 0) != hipSuccess)
@@ -2304,14 +2062,15 @@ static int multi_gather(rt_multi *m) {
     rt_context *c = m->ctx[i];
     if (!c->local_rows) continue;
     const uint32_t *src = b ? c->d_rgba8_alt : c->d_rgba8;
-    if (hipMemcpyPeerAsync(root->d_stack + ap.stack_offset[i], m->device0, src, c->device, c->local_rows * row_bytes, m->gather_stream) !=
+    const bool dry = (root->flags & 16) != 0;  // RT_OPT_FLAGS bit 4: the calls of a frame with next to none of its work
+    if (hipMemcpyPeerAsync(root->d_stack + ap.stack_offset[i], m->device0, src, c->device, (dry ? 1u : c->local_rows) * row_bytes, m->gather_stream) !=
         hipSuccess)
       return multi_fail(m, RT_ERR_DEVICE, "rt_multi: hipMemcpyPeerAsync failed");
   }
   ap.frame = root->d_frame;
   ap.own = b ? root->d_rgba8_alt : root->d_rgba8;
   ap.stack = root->d_stack;
-  if (launch_assemble(ap, m->gather_stream) != 0) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: assemble launch failed");
+  if (launch_assemble(ap, m->gather_stream, (root->flags & 16) != 0) != 0) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: assemble launch failed");
   if (hipEventRecord(m->done[b], m->gather_stream) != hipSuccess) return multi_fail(m, RT_ERR_DEVICE, "rt_multi: recording the gather event failed");
   for (uint32_t i = 0; i < n; ++i) m->ctx[i]->gather_pending[b] = true;  // target b is written again only after this gather
   return RT_OK;
@@ -2387,10 +2146,15 @@ int rt_multi_create(const int *device_ids, uint32_t n_devices, uint32_t strip_ro
     if (!c->multi_member) continue;
     c->gather_done[0] = m->done[0];
     c->gather_done[1] = m->done[1];
-    if (c->device != m->device0) {  // direct peer copies where the devices can (xGMI); otherwise the runtime stages them
+    if (c->device != m->device0) {  // direct peer copies where the devices can (xGMI); otherwise the runtime stages them through the host
       int can = 0;
-      if (hipDeviceCanAccessPeer(&can, m->device0, c->device) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(c->device, 0);
-      (void)hipGetLastError();  // "already enabled" is not an error
+      bool direct = false;
+      if (hipDeviceCanAccessPeer(&can, m->device0, c->device) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(c->device, 0);
+        direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+      }
+      (void)hipGetLastError();
+      (direct ? m->peers_direct : m->peers_staged) += 1u;  // reported by rt_multi_peer_status: a staged gather is visible, not silent
     }
   }
   if (n_devices > 1u) {
@@ -2405,6 +2169,12 @@ int rt_multi_create(const int *device_ids, uint32_t n_devices, uint32_t strip_ro
   return RT_OK;
 }
 
+int rt_multi_peer_status(rt_multi *m, uint32_t *direct, uint32_t *staged) {
+  if (!m || !direct || !staged) return RT_ERR_INVALID_ARGUMENT;
+  *direct = m->peers_direct;
+  *staged = m->peers_staged;
+  return RT_OK;
+}
 uint32_t rt_multi_device_count(rt_multi *m) { return m ? static_cast<uint32_t>(m->ctx.size()) : 0u; }
 rt_context *rt_multi_context(rt_multi *m, uint32_t index) { return (m && index < m->ctx.size()) ? m->ctx[index] : nullptr; }
 const char *rt_multi_last_error(rt_multi *m) { return m ? m->error.c_str() : "rt_multi is NULL"; }
@@ -2462,7 +2232,10 @@ int rt_multi_render_frames(rt_multi *m, uint32_t n_frames, const void *framedata
   if (!m) return RT_ERR_INVALID_ARGUMENT;
   {
     std::lock_guard<std::mutex> lock(m->random_mutex);  // every device launches with the same random texture
-    const int rc = multi_run(m, "rt_multi_render_frames", [=](rt_context *c) { return rt_render_frames(c, n_frames, framedata16); });
+    const int rc = multi_run(m, "rt_multi_render_frames", [=](rt_context *c) {
+      const int r = rt_render_frames(c, n_frames, framedata16);
+      return r == RT_OK ? multi_mark_ready(c) : r;
+    });
     if (rc != RT_OK) return rc;
   }
   return multi_gather(m);
@@ -2471,7 +2244,10 @@ int rt_multi_render_frame(rt_multi *m, const void *framedata16) {
   if (!m) return RT_ERR_INVALID_ARGUMENT;
   {
     std::lock_guard<std::mutex> lock(m->random_mutex);
-    const int rc = multi_run(m, "rt_multi_render_frame", [=](rt_context *c) { return rt_render_frame(c, framedata16); });
+    const int rc = multi_run(m, "rt_multi_render_frame", [=](rt_context *c) {
+      const int r = rt_render_frame(c, framedata16);
+      return r == RT_OK ? multi_mark_ready(c) : r;
+    });
     if (rc != RT_OK) return rc;
   }
   return multi_gather(m);
@@ -2480,7 +2256,10 @@ int rt_multi_render(rt_multi *m, float jitter_x, float jitter_y, uint32_t progre
   if (!m) return RT_ERR_INVALID_ARGUMENT;
   {
     std::lock_guard<std::mutex> lock(m->random_mutex);
-    const int rc = multi_run(m, "rt_multi_render", [=](rt_context *c) { return rt_render(c, jitter_x, jitter_y, progressive_count); });
+    const int rc = multi_run(m, "rt_multi_render", [=](rt_context *c) {
+      const int r = rt_render(c, jitter_x, jitter_y, progressive_count);
+      return r == RT_OK ? multi_mark_ready(c) : r;
+    });
     if (rc != RT_OK) return rc;
   }
   return multi_gather(m);

@@ -25,6 +25,8 @@ dev.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32 | N.RT_OUT_SEGMENTS | N.RT_OUT_
 dev.set_variant(variant)
 dev.set_option(N.RT_OPT_CULL, 2)
 dev.set_option(N.RT_OPT_GRID_MIN, F.grid_min_for(seed))
+for opt, val in list(F.dirmask_for(seed).items()) + list(F.dirlist_for(seed).items()):
+    dev.set_option(opt, val)
 target = RenderTarget.new(dev, size)
 rt = RandomTexture(dev)
 rt.write(rnd)
@@ -37,8 +39,9 @@ objects, count = (scene.live_object_bytes(), len(scene.objects)) if slots == "li
 ref = oracle.render(objects, count, scene.config_bytes(w, h), jitter, 0, sky, rnd, threads=8)
 got = target.read_hits(scene.reflection_limit)
 bad = np.argwhere((got != ref.hits).any(-1))
-print("seed %d: %d objects, size %s, R %d, variant used %d, cull mismatches %d, pixels with differing hit sequences %d"
-      % (seed, len(scene.objects), size, scene.reflection_limit, st.last_variant, st.last_cull_mismatches, len(bad)))
+print("seed %d: %d objects, size %s, R %d, variant used %d stage %d, cull mismatches %d, pixels with differing hit sequences %d; table %d x %d lists %d"
+      % (seed, len(scene.objects), size, scene.reflection_limit, st.last_variant, st.last_stage, st.last_cull_mismatches, len(bad), st.dirmask_cells,
+         st.dirmask_bins, st.dirmask_lists))
 first = {}
 for y, x in bad[:4000]:
     b = int(np.argmax(got[y, x] != ref.hits[y, x]))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Config 3 (1 024 spheres) by the candidate lists' options: Grays/s per (cells, bins per face edge, reach in cells).
+# Config 3 (1 024 spheres) by the candidate lists' options: Grays/s per (cells, bins per face edge, reach in cells, spill threshold).
 #   bash tools/dirlist_sweep.sh OUT.txt [spheres]
 OUT=$(realpath -m "$1"); N=${2:-1024}
 : > "$OUT"
@@ -8,12 +8,12 @@ run() { python bench.py $C "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('%-60s %8.1f Mrays/s  render %.3f ms (tail %.3f)' % (' '.join(sys.argv[1:]), d['value'], r['avg_launch_ms'], r.get('tail_avg_launch_ms') or 0))" "$@" >> "$OUT"; }
+run
 run --dirlist 0
-for cells in 2048 4096 8192 16384 32768 65536; do run --dirlist-cells $cells; done
-for k in 4 6 8 10 12; do run --dirlist-k $k; done
-for reach in 2 4 8 16 32 64; do run --dirlist-reach $reach; done
-run --dirlist-cells 4096 --dirlist-k 6
-run --dirlist-cells 8192 --dirlist-k 6 --dirlist-reach 8
-run --dirlist-cells 32768 --dirlist-k 6 --dirlist-reach 32
-for t in 0 16 32 48 64; do run --tail-spill $t; done
+for cells in 4096 8192 32768; do run --dirlist-cells $cells; done
+for k in 6 8 10 12; do for reach in 16 32; do run --dirlist-k $k --dirlist-reach $reach; done; done
+for t in 0 24 32 48 64 96; do run --tail-spill $t; done
+run --dirlist-k 10 --dirlist-reach 32 --tail-spill 48
+run --dirlist-k 12 --dirlist-reach 32 --tail-spill 48
+run --dirlist-k 12 --dirlist-reach 32 --tail-spill 64 --dirlist-cells 32768
 cat "$OUT"

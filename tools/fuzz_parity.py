@@ -58,11 +58,20 @@ def dirmask_for(seed):
             N.RT_OPT_DIRMASK_K: (1, 2, 4, 8, 16)[(seed // 3) % 5], N.RT_OPT_DIRMASK_CELLS: (1, 27, 512, 4096)[(seed // 7) % 4]}
 
 
+def dirlist_for(seed):
+    """RT_OPT_DIRLIST* of a case: candidate lists at every resolution and reach, every fourth case for small scenes too (from
+    one sphere up); off where the case forces the sphere grid (grid_min_for) and in every eleventh case."""
+    on = 0 if (seed % 3 == 1 or seed % 11 == 5) else 1
+    return {N.RT_OPT_DIRLIST: on, N.RT_OPT_DIRLIST_MIN: 1 if seed % 4 == 2 else 129,
+            N.RT_OPT_DIRLIST_K: (1, 2, 4, 8, 12)[(seed // 5) % 5], N.RT_OPT_DIRLIST_CELLS: (1, 27, 512, 16384, 100000)[(seed // 3) % 5],
+            N.RT_OPT_DIRLIST_REACH: (1, 2, 8, 32, 128)[(seed // 2) % 5]}
+
+
 def run(cases=100, first=0):
     dev = Device(0)
     multi = MultiDevice([0, 0, 0], 8)  # every seventh case also goes through three contexts of one process (rt_multi_*)
     sky = synth.procedural_skybox(128, 64)
-    bad = grids = tables = multis = spills = 0
+    bad = grids = tables = multis = spills = lists = 0
     for seed in range(first, first + cases):
         scene, size, jitter, slots, variant, tex_seed = random_case(seed)
         rnd = synth.random_texture(tex_seed)
@@ -72,7 +81,7 @@ def run(cases=100, first=0):
         dev.set_variant(variant)
         dev.set_option(N.RT_OPT_CULL, 2)
         dev.set_option(N.RT_OPT_GRID_MIN, grid_min_for(seed))
-        for opt, val in dirmask_for(seed).items():
+        for opt, val in list(dirmask_for(seed).items()) + list(dirlist_for(seed).items()):
             dev.set_option(opt, val)
         target = RenderTarget.new(dev, size)
         rt = RandomTexture(dev)
@@ -126,7 +135,7 @@ def run(cases=100, first=0):
                 print("  (in the %d-frame launch, first count %d, accum %d)" % (nf, pc0, accum), flush=True)
         if ok and seed % 7 == 3:  # the same frame, its row strips dealt over three contexts and gathered on the first
             multis += 1
-            for opt, val in dirmask_for(seed).items():
+            for opt, val in list(dirmask_for(seed).items()) + list(dirlist_for(seed).items()):
                 multi.set_option(opt, val)
             multi.set_option(N.RT_OPT_GRID_MIN, grid_min_for(seed))
             multi.set_accum_mode(N.RT_ACCUM_SRGB8)
@@ -148,16 +157,18 @@ def run(cases=100, first=0):
                      st.dirmask_cells, st.dirmask_bins),
                   flush=True)
         grids += st.last_stage == 3
-        tables += st.dirmask_cells != 0
+        tables += st.dirmask_cells != 0 and st.dirmask_lists == 0
+        lists += st.dirmask_lists != 0
         if (seed - first + 1) % 1000 == 0:  # a long soak must not look hung to the box's watchdog
             print("  ... %d cases, %d mismatching so far" % (seed - first + 1, bad), flush=True)
     dev.set_option(N.RT_OPT_CULL, 1)
     dev.set_option(N.RT_OPT_GRID_MIN, 129)
+    dev.set_option(N.RT_OPT_DIRLIST_MIN, 129)
     dev.close()
     multi.close()
-    print("fuzz: %d cases from seed %d (%d of them walked a sphere grid, %d used a direction-mask table, %d multi-frame launches "
-          "spilled their tail, %d also went through a three-context rt_multi), %d mismatching"
-          % (cases, first, grids, tables, spills, multis, bad), flush=True)
+    print("fuzz: %d cases from seed %d (%d of them walked a sphere grid, %d used a direction-mask table, %d candidate lists, %d multi-frame "
+          "launches spilled their tail, %d also went through a three-context rt_multi), %d mismatching"
+          % (cases, first, grids, tables, lists, spills, multis, bad), flush=True)
     return bad
 
 

@@ -21,8 +21,15 @@ rnd = synth.random_texture(1)
 jit = synth.jitter_sequence(42, 2048)
 
 
+DRY = "--dry" in sys.argv       # RT_OPT_FLAGS bit 4: every kernel runs one workgroup — the host's calls without the device's work
+TIMING = "--timing" in sys.argv  # keep the timing-only events of single-frame launches (RT_OPT_TIMING = 1, the library default)
+
+
 def measure(dev, label):
     dev.set_outputs(N.RT_OUT_RGBA8)
+    dev.set_option(N.RT_OPT_TIMING, 1 if TIMING else 0)
+    if DRY:
+        dev.set_option(N.RT_OPT_FLAGS, 16)
     RenderTarget.new(dev, (W, H))
     rt = RandomTexture(dev)
     rt.write(rnd)
@@ -36,9 +43,8 @@ def measure(dev, label):
             t0 = time.perf_counter()
             k = 0
             while k < frames:
-                if batch == 1:
-                    conn.frame_data.jitter, conn.frame_data.progressive_count = (float(jit[k, 0]), float(jit[k, 1])), k
-                    conn.draw()
+                if batch == 1:  # the raw C-ABI call, as a compiled host makes it
+                    dev._lib.rt_render(dev.handle, float(jit[k, 0]), float(jit[k, 1]), k)
                 else:
                     conn.draw_frames(jit[k:k + batch], k)
                 k += batch
