@@ -67,6 +67,28 @@ def algorithmic_flops(pixels, segments, n_objects):
     return segments * (25.0 * n_objects + 200.0) + 60.0 * pixels
 
 
+def usable_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            quota = float(fields[0]) if fields[0] != "max" else -1.0
+            period = float(fields[1]) if len(fields) > 1 else 100000.0
+            if path.endswith("cfs_quota_us"):
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = float(f.read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,9 +105,9 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tile-chunk", type=int, default=2)
     ap.add_argument("--flags", type=int, default=0)
-    ap.add_argument("--batch-inflight", type=int, default=1,
-                    help="RT_OPT_BATCH_INFLIGHT: multi-frame launches in flight (1 = one at a time, the library default: kernel "
-                         "times do not overlap; 2 = the next launch renders while this one resolves, +1..4 %% throughput)")
+    ap.add_argument("--batch-inflight", type=int, default=2,
+                    help="RT_OPT_BATCH_INFLIGHT: multi-frame launches in flight (2 = the library default: the next launch renders "
+                         "while this one's tail drains and resolves; 1 = one at a time: kernel times do not overlap)")
     ap.add_argument("--grid-min", type=int, default=0, help="RT_OPT_GRID_MIN: spheres from which a scene gets the sphere grid (0 = library default 129)")
     ap.add_argument("--dirmask", type=int, default=-1, help="RT_OPT_DIRMASK: 0 = secondary rays scan every sphere, 1 = direction-mask table (library default)")
     ap.add_argument("--dirmask-k", type=int, default=0, help="RT_OPT_DIRMASK_K (0 = library default)")
@@ -432,7 +454,7 @@ def main():
         prof_key = dict(prof.get("workload_key", {}))
         prof_key.pop("frames_per_launch", None)  # the profile's launches carried 8 frames; traffic is taken per frame
         tuned = (args.variant != -1 or args.dirmask >= 0 or args.dirmask_k or args.dirmask_cells or args.grid_min or args.flags or
-                 args.batch_inflight != 1 or args.blocks_per_cu or args.refill_min != 1 or args.tile_chunk != 2 or args.tail_spill >= 0 or args.tail_spill_single >= 0)
+                 args.batch_inflight != 2 or args.blocks_per_cu or args.refill_min != 1 or args.tile_chunk != 2 or args.tail_spill >= 0 or args.tail_spill_single >= 0)
         if prof_key != workload_key or B <= 1 or tuned:  # the profile was collected with the library's defaults
             continue
         if prof.get("kernel_source_sha256") != source_now:
@@ -550,8 +572,9 @@ def main():
             objects, count = scene.live_object_bytes(), len(scene.objects)
         else:
             objects, count = scene.as_bytes(W, H, args.slots)[0], args.slots
-        # the GPU box gives one GPU a share of 16 host cores; never use more than that
-        threads = max(1, min(oracle.max_threads(), os.cpu_count() or 1, 16))
+        # every host core this process may use (all cores, count stated): the CPUs of its affinity mask, capped by the
+        # cgroup's CPU quota where there is one (a GPU box gives one GPU a share of its host's cores)
+        threads = max(1, min(oracle.max_threads(), usable_cores()))
         cfg = scene.config_bytes(W, H)
         k0 = blk["first"]  # first frame of the median block: its first launch covers frames k0 .. k0+first_n-1
         oracle.render(objects, count, cfg, jit[k0 % n_jit], 0, sky, rnd, rows=(rows[0], rows[0] + 8),
@@ -571,9 +594,10 @@ def main():
             "value": round(cseg / cdt / 1e6, 3),
             "unit": "Mrays/s",
             "cores": threads,
+            "host_cores": os.cpu_count(),
             "kind": "port",
             "sample": "%d frame(s), rows %d..%d of the same %dx%d workload (%d segments, %.1f s wall, %d OpenMP "
-                      "threads), CPU oracle oracle/rt_oracle.c; the reference itself cannot run here (no "
+                      "threads = every core this process may use), CPU oracle oracle/rt_oracle.c built -O3 -fopenmp; the reference itself cannot run here (no "
                       "Rust/wgpu/Vulkan)" % (frames, rows[0], rows[1], W, H, cseg, cdt, threads),
         }
         # cross-check: the GPU counted the same number of segments for the frames of that launch

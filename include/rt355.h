@@ -106,6 +106,9 @@ typedef struct rt_device_buffers {
 RT355_API int rt_create(int device_id, rt_context **out_ctx);
 RT355_API int rt_destroy(rt_context *ctx);
 RT355_API uint32_t rt_abi_version(void);
+/* 1 in the A/B build (librt355_ab.so, `make -C rsraytracingv3_amd/csrc ab`), which also holds the launch shapes of finished A/Bs
+ * (RT_OPT_VARIANT 2 and 4); 0 in the shipped library, where those two values select the re-packing shape (3). */
+RT355_API int rt_has_ab_shapes(void);
 
 /* `Connection::load_hdri` (src/gpu/connection.rs:176-215): RGBA32F equirectangular
  * panorama, tightly packed rows, row 0 = top.  Sampled nearest / clamp-to-edge
@@ -330,10 +333,10 @@ RT355_API int rt_present_wait(rt_context *ctx, uint32_t slot, const void **texel
 /* Tuning knobs; results are bit-identical for every setting, only speed changes. */
 enum {
   RT_OPT_VARIANT = 0,      /* -1 (default) choose per launch; 0 one 8x8 tile per wave, sphere records in
-                              LDS; 1 same, records from global memory; 2 resident waves that refill
-                              finished lanes; 3 tiles whose workgroup re-packs surviving paths; 4 streamed
-                              (sample-only launches: primary pass -> path queue in global memory -> resident
-                              waves refilled from the queue after every bounce; else falls back to 3)        */
+                              LDS; 1 same, records from global memory; 3 tiles whose workgroup re-packs surviving paths.
+                              Only in the A/B build (rt_has_ab_shapes; the shipped library runs 3 for both): 2 resident waves that
+                              refill finished lanes; 4 streamed (sample-only launches: primary pass -> path queue in global
+                              memory -> resident waves refilled from the queue after every bounce; else falls back to 3)  */
   RT_OPT_REFILL_MIN = 1,   /* variants 2 and 4: idle lanes a wave tolerates before pulling work (1..64) */
   RT_OPT_BLOCKS_PER_CU = 2,/* variants 2 and 4: resident workgroups per CU (0 = occupancy query) */
   RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump; variant 4: 64-path
@@ -387,11 +390,12 @@ enum {
                              * 0: single-frame launches in flight record none that only serve those queries (their kernel times read 0):
                              * a frame then costs the host six HIP calls, 16 us instead of 27 (tools/microbench/host_calls.hip) — what a
                              * render loop that never asks for kernel times wants when a rank's share of a frame is a few microseconds */
-  RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 1): as RT_OPT_INFLIGHT,
+  RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 2): as RT_OPT_INFLIGHT,
                               each launch staging its samples in a buffer of its own; the history is updated in frame
-                              order on the context's stream.  2 hides the resolve pass and the gap between launches
-                              behind the next launch (+1 ... +4 % throughput at 1080p) at the price of a second staging
-                              buffer and of kernel times that overlap (rt_get_launch_span).                        */
+                              order on the context's stream.  2 hides the resolve pass, the tail of a launch and the gap to the
+                              next one behind the next launch's rendering (+4 ... +7 % throughput at 1080p) at the price of a
+                              second staging buffer and of kernel times that overlap (rt_get_launch_span gives the device time);
+                              1 = one launch at a time.                                                                 */
 };
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */

@@ -73,6 +73,7 @@ class RtDeviceBuffers(C.Structure):
 _vp, _u32, _i, _f, _sz = C.c_void_p, C.c_uint32, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "rt_abi_version": (_u32, []),
+    "rt_has_ab_shapes": (_i, []),
     "rt_create": (_i, [_i, C.POINTER(_vp)]),
     "rt_destroy": (_i, [_vp]),
     "rt_set_skybox": (_i, [_vp, _u32, _u32, _vp]),

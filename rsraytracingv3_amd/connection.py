@@ -145,7 +145,7 @@ class _MultiLib:
     """``rt_x(handle, ...)`` -> ``rt_multi_x(handle, ...)``, so that Connection / RenderTarget / RandomTexture drive an
     ``rt_multi`` with the calls they make on one device.  ``rt_read_rgba8`` is the assembled frame (all rows are local to
     the rt_multi as a whole); calls without a multi-device form raise."""
-    _NO_HANDLE = ("rt_exr_last_error", "rt_exr_read_rgba32f", "rt_exr_free", "rt_abi_version")
+    _NO_HANDLE = ("rt_exr_last_error", "rt_exr_read_rgba32f", "rt_exr_free", "rt_abi_version", "rt_has_ab_shapes")
 
     def __init__(self, lib):
         self._real = lib

@@ -20,6 +20,7 @@ using namespace rt355;
 
 extern "C" {
 uint32_t rt_abi_version(void) { return RT355_ABI_VERSION; }
+int rt_has_ab_shapes(void) { return 0; }
 // (rt_set_skybox_exr, in rt_exr.cpp, hands the decoded image to the device side: there is none in this library)
 int rt_set_skybox(rt_context *, uint32_t, uint32_t, const float *) { return RT_ERR_NO_DEVICE; }
 #include "rt_host_twins.h"

@@ -83,7 +83,8 @@ constexpr int kDefaultDirlistReach = 32;       // RT_OPT_DIRLIST_REACH: the larg
 constexpr int kDefaultTailSpillLists = 24;     // RT_OPT_TAIL_SPILL of scenes with candidate lists (one-wave workgroups: 16 / 24 / 32: 37.7 / 37.8 / 37.4)
 constexpr int kDefaultGridMinSpheres = 129;    // RT_OPT_GRID_MIN
 constexpr int kDefaultInflight = 4;            // RT_OPT_INFLIGHT
-constexpr int kDefaultBatchInflight = 1;       // RT_OPT_BATCH_INFLIGHT
+constexpr int kDefaultBatchInflight = 2;       // RT_OPT_BATCH_INFLIGHT: the next multi-frame launch renders while this one's tail drains and resolves
+                                               // (round 3: 53.9 -> 57.8 Grays/s on the headline; one at a time: kernel times that do not overlap)
 constexpr int kDefaultTailSpillSingle = 0;     // RT_OPT_TAIL_SPILL_SINGLE: single frames in flight do not spill (A/B on one device, one frame per
                                                // launch, threshold 0 / 32: 47.0 / 47.4 - 48.0 Grays/s in runs of 200 frames, 45.1 / 43.3 in runs of 20:
                                                // tail_stream's fixed ~35 us per launch pay only in long uninterrupted runs)
@@ -194,6 +195,7 @@ struct LaunchConfig {
   int flags;              // reserved for experiment switches
 };
 int persistent_blocks_per_cu(size_t lds_bytes);
+bool has_ab_shapes();  // built with -DRT_AB_SHAPES: the resident-wave (2) and streamed (4) launch shapes exist
 // event-count build only (make events): counts since the last reset — see RT_CNT in rt_kernels.hip; zeros otherwise
 int prof_counts(unsigned long long out8[8], bool reset);
 // The launch shape launch_render will use for this launch (the auto rule, and the fall-backs of a forced variant),

@@ -95,7 +95,9 @@ namespace {
                                // whole wave executes) in path_end, with the other finished lanes, 0 = at the miss after every
                                // bounce.  A/B on one device: +1.6 % (it cost 4 % while the kernel had no register to spare)
 #endif
-constexpr int kBlock = 256;
+#ifdef RT_AB_SHAPES
+constexpr int kBlock = 256;  // threads per workgroup of the resident-wave shape
+#endif
 #ifndef RT_TILES_BLOCK
 #define RT_TILES_BLOCK 256
 #endif
@@ -112,9 +114,6 @@ constexpr int kTile = 8;  // 8x8 pixels per tile / wave
 #endif
 #ifndef RT_MASK_PIPELINE
 #define RT_MASK_PIPELINE 1  // direction-mask scans: request the next candidate's record before the current one is tested
-#endif
-#ifndef RT_PACK_HITS
-#define RT_PACK_HITS 1  // re-packing shape: pack the paths that hit between the scan and the shading (0: after the shading)
 #endif
 #ifndef RT_BLOCK_NW_LISTS
 #define RT_BLOCK_NW_LISTS 1  // ... of the kernels of large scenes (candidate lists, nothing staged): ONE wave.  Two waves share a staged scene
@@ -135,7 +134,7 @@ constexpr uint32_t kScanScratchBytes = 64u * 16u + 64u * 8u + 64u * 8u + kPairCa
 // entries as loaded, and up to 64 x 15 (lane, position) pairs
 constexpr uint32_t kListPairCap = 64u * kDirListSlots;
 constexpr uint32_t kListScratchBytes = 64u * 16u + 64u * 8u + 64u * 8u + 64u * 32u + kListPairCap * 2u;  // 6016
-constexpr uint32_t xchg_bytes(uint32_t nw) { return xchg_paths(nw) * (RT_PACK_HITS ? 5u : 4u) * 16u; }
+constexpr uint32_t xchg_bytes(uint32_t nw) { return xchg_paths(nw) * 5u * 16u; }
 // With two waves per workgroup the scratch may share the exchange buffer's LDS: the buffer is only written after a count
 // barrier that both waves reach after their scans, and once it has been used a single wave is left.  Other workgroup sizes
 // keep the two apart.
@@ -1546,6 +1545,7 @@ __device__ __forceinline__ void add_totals(const FrameParams &fp, uint32_t seg, 
 struct TilePos {
   uint32_t col, row, frame;
 };
+#ifdef RT_AB_SHAPES  // (only the resident-wave shape numbers its tiles linearly)
 __device__ __forceinline__ TilePos tile_pos(const FrameParams &fp, uint32_t tile, uint32_t tiles_x) {
   TilePos t;
   const uint32_t stacked_row = tile / tiles_x;
@@ -1554,6 +1554,7 @@ __device__ __forceinline__ TilePos tile_pos(const FrameParams &fp, uint32_t tile
   t.row = stacked_row - t.frame * fp.frame_tile_rows;
   return t;
 }
+#endif
 
 // The tile kernels are launched on a 3-D grid — x: tile column / waves per workgroup, y: tile row, z: frame of the batch —
 // so that a wave's tile needs no integer division (tile_pos costs ~50 vector instructions per wave: two 32-bit
@@ -1632,8 +1633,7 @@ __global__ void __launch_bounds__(THREADS) render_tiles(DeviceScene sc, FramePar
 // s_barrier drops ended waves from its count (tools/microbench/barrier_exit.hip), and their registers and
 // wave slots go to the next workgroup — then the hits are shaded.  Path lengths vary 1..R, so without this
 // most of a tile's later scans run with a handful of live lanes.  Pixel results do not depend on which
-// lane finishes a path, so the frame stays bit-identical.  (RT_PACK_HITS 0: count and pack the survivors after
-// the shading instead.)
+// lane finishes a path, so the frame stays bit-identical.
 // LISTS: a large scene — nothing is staged (records and materials come from memory through the vector cache: a thousand spheres'
 // records alone would cost the workgroups their occupancy), secondary rays use the candidate lists; LDS holds the exchange buffer
 // and the two waves' list-scan scratch.
@@ -1689,7 +1689,6 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   // stores, ~150 instructions) together with the other finished lanes when the lane is about to be
   // re-used or the wave ends, not one partial-wave call per bounce.
   bool finished = false;
-#if RT_PACK_HITS
   // Every bounce: scan -> the paths that missed end -> the workgroup counts the paths that HIT and packs them into fewer
   // waves when they fit -> shade.  Packing between the scan and the shading (instead of after the shading) spares the
   // surplus wave its shading pass: the misses, a third of the rays of a bounce, have left by then.
@@ -1814,71 +1813,6 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
     }
     RT_PH_MARK(3)
   }
-#else
-  for (;;) {
-    {
-      const bool was = alive;
-      alive = path_step_wave<RT_DEFER_SKY_BLOCKS, false, LEAN>(sv, fp, s, alive, primary_mask, primary_mask2 RT_PH_ARGS);
-      primary_mask = nullptr;  // only the first segment is a primary ray of this wave's tile
-      rough_total += s.rough & 0x7fffffffu;
-      s.rough &= 0x80000000u;  // keeps "ended on a miss" (the skybox is sampled in path_end)
-      finished |= was & !alive;
-    }
-    unsigned int *counts = wave_count[iters & 1u];
-    iters += 1u;
-    const unsigned long long live = __builtin_amdgcn_ballot_w64(alive);
-    if (lane == 0) counts[wave] = static_cast<uint32_t>(__popcll(live));
-    __syncthreads();
-    RT_PH_MARK(4)
-    uint32_t total = 0, before = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const uint32_t c = (static_cast<uint32_t>(w) < live_waves) ? counts[w] : 0u;
-      before += (static_cast<uint32_t>(w) < wave) ? c : 0u;
-      total += c;
-    }
-    if (total == 0u) break;
-    const uint32_t need = (total + 63u) >> 6;
-    if (need < live_waves && total <= xchg_paths(NW)) {
-      // pack: path number = paths in lower waves + live lanes below this one
-      if (alive) {
-        const uint32_t r = before + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(live >> 32),
-                                                              __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(live), 0u));
-        float4 *q = xchg + 4u * r;
-        q[0] = make_float4(s.o.x, s.o.y, s.o.z, s.d.x);
-        q[1] = make_float4(s.d.y, s.d.z, s.energy.x, s.energy.y);
-        q[2] = make_float4(s.energy.z, s.result.x, s.result.y, s.result.z);
-        q[3] = make_float4(s.rng.seed, s.rng.px, s.rng.py, __uint_as_float(s.p | (s.seg << 26)));
-      }
-      if (finished) {  // the lane's registers are about to change hands
-        path_end<RT_DEFER_SKY_BLOCKS, LEAN>(fp, s);
-        seg_total += s.seg;
-        finished = false;
-      }
-      __syncthreads();
-      if (wave >= need) break;  // surplus wave: its paths now live in a lower wave
-      const uint32_t r = wave * 64u + lane;
-      alive = r < total;
-      if (alive) {
-        const float4 *q = xchg + 4u * r;
-        const float4 a = q[0], b = q[1], c = q[2], e = q[3];
-        s.o = mk3(a.x, a.y, a.z);
-        s.d = mk3(a.w, b.x, b.y);
-        s.energy = mk3(b.z, b.w, c.x);
-        s.result = mk3(c.y, c.z, c.w);
-        s.rng = Rng{e.x, e.y, e.z};
-        const uint32_t packed = __float_as_uint(e.w);
-        s.p = packed & 0x03ffffffu;
-        s.seg = packed >> 26;
-        s.rough = 0;
-      }
-      live_waves = need;
-      // No barrier here: the exchange buffer is next written after the next count barrier, which the
-      // surviving waves only pass once their reads above have completed.
-      RT_PH_MARK(5)
-    }
-  }
-#endif
   RT_PH_MARK(5)
   if (finished) {
     path_end<RT_DEFER_SKY_BLOCKS, LEAN>(fp, s);
@@ -1902,6 +1836,9 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
 #endif
 }
 
+// ---- launch shapes of finished A/Bs (RT_OPT_VARIANT 2 and 4): compiled only with -DRT_AB_SHAPES (`make ab` -> librt355_ab.so, which the
+// A/B tools and tests/test_ab_shapes_gpu.py use); the shipped library maps both to the re-packing shape -------------------------------
+#ifdef RT_AB_SHAPES
 // Streamed shape (variant 4), for launches of several frames that write float samples only.  Two kernels:
 //   primary_stream  one 8x8 tile per wave: the primary segment with the tile's culled sphere list, exactly as
 //                   render_blocks' first iteration; paths that end there are written out, the others are appended
@@ -2090,6 +2027,8 @@ __global__ void __launch_bounds__(NW * 64, WAVES) bounce_stream(DeviceScene sc, 
   RT_PH_FLUSH(fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride)
 }
 
+#endif  // RT_AB_SHAPES
+
 // Tail of the re-packing shape (FrameParams::spill_max): render_blocks' workgroups hand the last few paths of their tiles —
 // the ones that would otherwise bounce on in a mostly empty wave, each with the hit its scan has just found — to the path
 // queue; resident waves here take them off it in chunks, SHADE them (every lane that carries a path carries a pending hit),
@@ -2259,6 +2198,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, Fr
   RT_PH_FLUSH(fp.counters + static_cast<size_t>(blockIdx.x % kTotalShards) * kTotalShardStride)
 }
 
+#ifdef RT_AB_SHAPES
 // Resident waves + lane refill.  `refill_min`: idle lanes a wave tolerates before it pulls
 // new pixels (1 = refill at once).  fp.tile_counters: 8 counters, 128 B apart, zero at launch.
 __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent(DeviceScene sc, FrameParams fp, uint32_t refill_min,
@@ -2365,6 +2305,8 @@ __global__ void __launch_bounds__(kBlock, RT_PERSISTENT_WAVES) render_persistent
   }
   add_totals(fp, seg_total, rough_total, wave_iters);
 }
+
+#endif  // RT_AB_SHAPES
 
 // Primary-ray culling pre-pass.  The rays of one pixel column lie in a plane through the camera
 // (pixel_world_space is affine in v, ray.hlsl:31-35), and so do the rays of one pixel row, so a tile's
@@ -2664,9 +2606,14 @@ uint64_t launch_tiles(const FrameParams &fp) {
 }  // namespace
 
 uint32_t stream_queue_shard_cap(const FrameParams &fp) {
+#ifndef RT_AB_SHAPES
+  (void)fp;
+  return 0u;  // (the streamed shape lives in the A/B build only)
+#else
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile, tiles_y = (fp.local_rows + kTile - 1) / kTile;
   const uint64_t blocks = static_cast<uint64_t>((tiles_x + RT_STREAM_NW1 - 1) / RT_STREAM_NW1) * tiles_y * fp.batch;  // primary_stream's grid
   return static_cast<uint32_t>((blocks + kQueueShards - 1) / kQueueShards) * RT_STREAM_NW1 * 64u;
+#endif
 }
 
 int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc) {
@@ -2687,16 +2634,18 @@ int pick_variant(const DeviceScene &sc, const FrameParams &fp, const LaunchConfi
     const uint64_t enough = fp.batch > 1u ? 20000ull : (sc.dm.enabled ? 4000ull : 24000ull);
     // up to 128 spheres (+ 8 padding records), or a large scene with candidate lists
     variant = (((sc.n_sph_pad > 136u || sc.grid.enabled) && !sc.dm.lists) || tiles < enough) ? 0 : 3;
-#if RT_STREAM_MIN_TILES
+#if defined(RT_AB_SHAPES) && RT_STREAM_MIN_TILES
     if (variant == 3 && tiles >= RT_STREAM_MIN_TILES && sample_only(fp)) variant = 4;
 #endif
   }
+#ifndef RT_AB_SHAPES
+  if (variant == 2 || variant == 4) variant = 3;  // (the resident-wave and streamed shapes live in the A/B build only)
+#endif
   // the streamed shape writes float samples only and needs its queue
   if (variant == 4 && !sample_only(fp)) variant = 3;
   // the packed path state of the streamed shape (and of the re-packing shape when it packs after the shading) keeps 6 bits of
   // bounce count and 26 bits of pixel index; the default re-packing shape carries both in full
-  if ((variant == 4 || (variant == 3 && !RT_PACK_HITS)) && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26)))
-    variant = variant == 4 && RT_PACK_HITS ? 3 : 0;
+  if (variant == 4 && (fp.reflection_limit > 63u || tiles * (kTile * kTile) > (1ull << 26))) variant = 3;
   // the streamed and resident-wave shapes have no candidate-list form, nor have the tiles that read everything from memory
   if ((variant == 2 || variant == 4) && sc.dm.lists) variant = 3;
   if (variant == 1 && sc.dm.lists) variant = 0;
@@ -2724,6 +2673,7 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
   if (variant == 4 && fp.queue == nullptr) variant = 3;  // no queue handed in: the re-packing shape serves
   if (variant_used) *variant_used = variant;
   if (stage_used) *stage_used = 2;  // the re-packing and resident-wave shapes stage the whole image
+#ifdef RT_AB_SHAPES
   if (variant == 2) {
     uint32_t blocks = static_cast<uint32_t>(lc.persistent_blocks);
     const uint64_t max_useful = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
@@ -2740,7 +2690,9 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     const uint32_t chunk = 64u * static_cast<uint32_t>(lc.tile_chunk < 1 ? 1 : lc.tile_chunk);
     hipLaunchKernelGGL((bounce_stream<RT_STREAM_NW2, RT_STREAM_WAVES>), dim3(blocks2), dim3(RT_STREAM_NW2 * 64), lds_image, stream, sc,
                        fp, static_cast<uint32_t>(lc.refill_min), chunk);
-  } else if (variant == 3) {
+  } else
+#endif
+  if (variant == 3) {
     // (RT_OPT_FLAGS bit 4, "dry" launches: one workgroup per kernel — all of a launch's host work, next to none of its rendering)
     const bool lists = sc.dm.enabled && sc.dm.lists;
     const uint32_t nw = lists ? RT_BLOCK_NW_LISTS : RT_BLOCK_NW;
@@ -2858,7 +2810,7 @@ int launch_dirlist_build(const DirMaskParams &dm, const float4 *reg, uint32_t n,
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap) {
   if (shard_cap) *shard_cap = 0;
   // sample-only launches of the re-packing shape whose secondary rays use the balanced scan (tail_stream has its scratch)
-  if (wanted == 0u || !RT_PACK_HITS || !sample_only(fp) || !sc.dm.enabled || pick_variant(sc, fp, lc) != 3) return 0u;
+  if (wanted == 0u || !sample_only(fp) || !sc.dm.enabled || pick_variant(sc, fp, lc) != 3) return 0u;
   // nothing to hand over when the first shading is the last; and tail_stream costs a launch ~35 us whatever it holds, which
   // small launches do not earn back (RT_OPT_FLAGS bit 2 lifts the size rule: tests)
   if (fp.reflection_limit < 2u || (launch_tiles(fp) < kTailMinTiles && !(lc.flags & 4))) return 0u;
@@ -2884,11 +2836,16 @@ int tail_blocks_per_cu(size_t lds_bytes, bool lists) {
 }
 
 int stream_blocks_per_cu(size_t lds_bytes) {
+#ifdef RT_AB_SHAPES
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, bounce_stream<RT_STREAM_NW2, RT_STREAM_WAVES>, RT_STREAM_NW2 * 64, lds_bytes) !=
       hipSuccess)
     return 0;
   return n;
+#else
+  (void)lds_bytes;
+  return 0;
+#endif
 }
 
 int prof_counts(unsigned long long out8[8], bool reset) {
@@ -2906,9 +2863,22 @@ int prof_counts(unsigned long long out8[8], bool reset) {
 }
 
 int persistent_blocks_per_cu(size_t lds_bytes) {
+#ifdef RT_AB_SHAPES
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, render_persistent, kBlock, lds_bytes) != hipSuccess) return 0;
   return n;
+#else
+  (void)lds_bytes;
+  return 0;
+#endif
+}
+
+bool has_ab_shapes() {
+#ifdef RT_AB_SHAPES
+  return true;
+#else
+  return false;
+#endif
 }
 
 int launch_random_fill(float *dst, uint32_t count, unsigned long long seed, hipStream_t stream) {

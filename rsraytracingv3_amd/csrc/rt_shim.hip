@@ -516,6 +516,7 @@ extern "C" {
 static void release_comm(rt_context *ctx, int patience_ms, bool always_abort = false);
 
 uint32_t rt_abi_version(void) { return RT355_ABI_VERSION; }
+int rt_has_ab_shapes(void) { return has_ab_shapes() ? 1 : 0; }
 
 int rt_create(int device_id, rt_context **out_ctx) {
   if (!out_ctx) return RT_ERR_INVALID_ARGUMENT;
