@@ -442,7 +442,7 @@ def main():
     traffic = traffic_resolve = issue_util = traffic_source = None
     workload_key = {"width": W, "height": H, "objects": n_objects, "bounces": args.bounces, "sky_width": args.sky, "n_gpus": world}
     source_now = N.kernel_source_hash()
-    for name in ("traffic_r03.json", "traffic_r02.json"):
+    for name in ("traffic_r04.json", "traffic_r04_config3.json", "traffic_r03.json", "traffic_r02.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tpath) or traffic is not None:
             continue
@@ -454,6 +454,7 @@ def main():
         prof_key = dict(prof.get("workload_key", {}))
         prof_key.pop("frames_per_launch", None)  # the profile's launches carried 8 frames; traffic is taken per frame
         tuned = (args.variant != -1 or args.dirmask >= 0 or args.dirmask_k or args.dirmask_cells or args.grid_min or args.flags or
+                 args.dirlist >= 0 or args.dirlist_k or args.dirlist_cells or args.dirlist_reach or
                  args.batch_inflight != 2 or args.blocks_per_cu or args.refill_min != 1 or args.tile_chunk != 2 or args.tail_spill >= 0 or args.tail_spill_single >= 0)
         if prof_key != workload_key or B <= 1 or tuned:  # the profile was collected with the library's defaults
             continue

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""What rt_set_scene costs with the direction-mask table: first call (table built on the device), a call with the same
-spheres (a moving camera: table kept), a call with one sphere moved (rebuilt).  python tools/set_scene_time.py [k] [cells]"""
+"""What rt_set_scene costs with the direction-mask table (64 spheres) and with the candidate lists (1 024 spheres): first call
+(table built on the device), a call with the same spheres (a moving camera: table kept), a call with one sphere moved (rebuilt).
+python tools/set_scene_time.py [k] [cells]"""
 import os
 import sys
 import time
@@ -38,15 +39,24 @@ def timed(label):
     print("%-46s %8.3f ms   (table %d cells x %d bins)" % (label, dt * 1e3, st.dirmask_cells, st.dirmask_bins), flush=True)
 
 
-for on in (1, 0):
+def run_case(on):
     dev.set_option(N.RT_OPT_DIRMASK, on)
-    timed("dirmask %d: first rt_set_scene" % on)
+    n = len(scene.objects) - 1
+    timed("%d spheres, tables %d: first rt_set_scene" % (n, on))
     conn.draw(); dev.sync()
-    timed("dirmask %d: same spheres again" % on)
+    timed("%d spheres, tables %d: same spheres again" % (n, on))
     scene.camera.position = (56.0, 65.0, 55.0)
-    timed("dirmask %d: camera moved" % on)
+    timed("%d spheres, tables %d: camera moved" % (n, on))
     c = scene.objects[3].geometry.center
     scene.objects[3].geometry.center = (c[0] + 0.5, c[1], c[2])
-    timed("dirmask %d: one sphere moved" % on)
+    timed("%d spheres, tables %d: one sphere moved" % (n, on))
     conn.draw(); dev.sync()
+
+
+for on in (1, 0):
+    run_case(on)
+scene = cases.stress_scene(1024, 8)  # candidate lists (tables 1) against the sphere grid (tables 0)
+conn = Connection(scene, dev, synth.procedural_skybox(256, 128), rt, max_objects="live")
+for on in (1, 0):
+    run_case(on)
 dev.close()
