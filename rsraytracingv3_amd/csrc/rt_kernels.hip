@@ -1014,7 +1014,7 @@ __device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const Frame
 // not serve (direction not a unit vector, NaN, farther along than s_cap, an entry without a reach) scan linearly at the end,
 // together (the cooperative scan when they are few).  The planes are tested under the first round's load.
 // `scratch_base`: kListScratchBytes per wave.
-template <bool LEAN>
+template <bool LEAN, bool TRIPS2 = (RT_LIST_TRIPS2 != 0)>
 __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const FrameParams &fp, f3 o, f3 d, bool alive, Hit miss,
                                                 unsigned char *scratch_base RT_PH_PARAMS) {
   const DirMaskParams &dm = *sv.dm;
@@ -1110,7 +1110,7 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     RT_PHL(2)
-#if RT_LIST_TRIPS2
+    if (TRIPS2) {
     // two pairs per lane and trip: the two chains of dependent reads (pair -> slot -> sphere record, the last one from memory) are
     // in flight together.  Lanes beyond the list read pair 0's operands (always there when total > 0) and drop the result.
     for (uint32_t first = 0u; first < total; first += 128u) {  // wave-uniform trip count
@@ -1141,7 +1141,7 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
         }
       }
     }
-#else
+    } else {
     for (uint32_t first = 0u; first < total; first += 64u) {  // wave-uniform trip count
       const uint32_t j = first + lane;
       if (j < total) {
@@ -1160,7 +1160,7 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
         }
       }
     }
-#endif
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1424,7 +1424,7 @@ __device__ __forceinline__ bool path_step_wave(const SceneView &sv, const FrameP
 // for — the tile's culled list for primary rays, the cooperative scan at <= 32 live rays, the full scan otherwise — and
 // the planes.  `alive` lanes get their Hit (obj -1 = miss); the others get a miss.  Used by render_blocks, which packs the
 // paths that HIT before it shades them.
-template <bool LEAN, bool LISTS = false>
+template <bool LEAN, bool LISTS = false, bool TRIPS2 = (RT_LIST_TRIPS2 != 0)>
 __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FrameParams &fp, const Path &s, bool alive,
                                               const unsigned long long *__restrict__ primary_mask,
                                               const unsigned long long *__restrict__ primary_mask2, unsigned char *scratch RT_PH_PARAMS) {
@@ -1450,7 +1450,7 @@ __device__ __forceinline__ Hit path_scan_wave(const SceneView &sv, const FramePa
     RT_PH_MARK(0)
   } else if (LISTS) {
     // secondary rays of a large scene: candidate lists, in rounds (rt_dirmask.h)
-    h = intersect_listed<LEAN>(sv, fp, s.o, s.d, alive, h, scratch RT_PH_ARGS);
+    h = intersect_listed<LEAN, TRIPS2>(sv, fp, s.o, s.d, alive, h, scratch RT_PH_ARGS);
     RT_PH_MARK(1)
   } else if (uint32_t entry = 0u; sv.dm->enabled != 0u && sv.dm->lists == 0u && dirmask_lookup(*sv.dm, s.o, s.d, alive, entry)) {
     // secondary rays of a small scene: every lane tests its own candidate set (rt_dirmask.h)
@@ -2042,8 +2042,19 @@ __global__ void __launch_bounds__(NW * 64, WAVES) bounce_stream(DeviceScene sc, 
 #define RT_TAIL_WAVES 5  // waves per SIMD tail_stream is budgeted for (96 registers, no scratch; 6: 52 B, 7: 92 B of scratch per lane —
                          // A/B on one device at threshold 32: 53.0 / 51.8 / 49.3 Grays/s)
 #endif
+// tail_stream on a scene with candidate lists: what counts there is the number of waves that wait side by side (it is a third of a
+// 1 024-sphere launch and issues a quarter of the time), not the work in flight inside one: ONE pair per lane and trip and the random()
+// texel requested at the shading — twelve registers fewer — fit 5 waves per SIMD with 12 B of scratch.  A/B on one device, 1 024
+// spheres, two launches in flight / one: 4 waves with two pairs + early texel 40.0 / 38.5 Grays/s, 5 waves with them (36 B of scratch)
+// 40.3 / 37.8, 5 waves without 41.2 / 38.7, 6 waves without (84 B) 37.2 / 35.2.
+#ifndef RT_TAIL_TRIPS2
+#define RT_TAIL_TRIPS2 0
+#endif
+#ifndef RT_TAIL_EARLY_X
+#define RT_TAIL_EARLY_X 0
+#endif
 #ifndef RT_TAIL_WAVES_LISTS
-#define RT_TAIL_WAVES_LISTS 4  // ... with candidate lists (128 registers, no scratch; at 5 it spills 32 B per lane: A/B on one device 34.5 / 34.35 Grays/s)
+#define RT_TAIL_WAVES_LISTS 5
 #endif
 template <int NW, int WAVES, bool LISTS = false>
 __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, FrameParams fp, uint32_t refill_min, uint32_t chunk) {
@@ -2081,7 +2092,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, Fr
   bool work_left = true;
   // large scenes (the kernel waits on memory): a surviving path's first random() texel is requested right after its scan, a whole
   // refill ahead of the shading that uses it
-  constexpr bool EARLY_X = LISTS && RT_LIST_EARLY_X;
+  constexpr bool EARLY_X = LISTS && RT_TAIL_EARLY_X;
   float x1_early = 0.0f;
   bool has_x1 = false;
   uint32_t seg_total = 0, rough_total = 0, wave_iters = 0;
@@ -2168,7 +2179,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) tail_stream(DeviceScene sc, Fr
     }
     RT_PH_MARK(3)
     __builtin_amdgcn_s_setprio(1);
-    h = path_scan_wave<true, LISTS>(sv, fp, s, alive, nullptr, nullptr, scratch RT_PH_ARGS);
+    h = path_scan_wave<true, LISTS, (RT_TAIL_TRIPS2 != 0)>(sv, fp, s, alive, nullptr, nullptr, scratch RT_PH_ARGS);
     if (alive && h.obj < 0) {  // frag.hlsl:14-17: a miss ends the path (its skybox texel is fetched in path_end)
       (void)path_shade<RT_DEFER_SKY_BLOCKS, true>(sv, fp, s, h, 0.0f, 0.0f, 0.0f);
       alive = false;

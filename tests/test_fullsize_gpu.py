@@ -104,13 +104,50 @@ def test_reference_padding_is_invisible_at_1080p(device):
 
 
 def test_stress_1024_spheres_at_1080p_shapes_agree(device):
+    """BASELINE config 3 at its full size: the candidate lists in the re-packing shape (the shape its launches take), in the plain
+    tile shape and switched off (the sphere grid of round 3) give one and the same frame and segment total; an eight-frame launch
+    (one-wave workgroups that spill their tails to tail_stream) equals eight single frames; and a 64-row band of the frame equals
+    the oracle's, texel for texel."""
     scene = cases.stress_scene(1024, 8)
-    sums = []
-    for variant in (2, 3):
-        t, st = render(device, scene, (1920, 1080), (0.1, 0.1), variant=variant)
-        assert st.sphere_count == 1024
-        sums.append((crc(t.read_rgba8()), st.last_segments))
-    assert sums[0] == sums[1]
+    size, jitter = (1920, 1080), (0.1, 0.1)
+    sums = {}
+    try:
+        for name, variant, lists in (("lists, re-packing", 3, 1), ("lists, tiles", 0, 1), ("grid", -1, 0)):
+            device.set_option(N.RT_OPT_DIRLIST, lists)
+            t, st = render(device, scene, size, jitter, variant=variant)
+            assert st.sphere_count == 1024 and (st.dirmask_lists > 0) == bool(lists) and (st.grid_cells > 0) != bool(lists)
+            sums[name] = (crc(t.read_rgba8()), st.last_segments)
+            if name == "lists, re-packing":
+                band = t.read_rgba8(rows=(512, 64))
+        assert sums["lists, re-packing"] == sums["lists, tiles"] == sums["grid"], sums
+    finally:
+        device.set_option(N.RT_OPT_DIRLIST, 1)
+    ref = oracle.render(scene.live_object_bytes(), len(scene.objects), scene.config_bytes(*size), jitter, 0, sky(), synth.random_texture(1),
+                        rows=(512, 576), threads=8, want_hits=False)
+    assert np.array_equal(band, ref.rgba8[512:576])
+    # eight frames in one launch against eight launches
+    device.set_outputs(N.RT_OUT_RGBA8)
+    device.set_variant(-1)
+    jit = synth.jitter_sequence(3, 8)
+    results = []
+    for batched in (False, True):
+        target = RenderTarget.new(device, size)
+        rt = RandomTexture(device)
+        rt.write(synth.random_texture(1))
+        conn = Connection(scene, device, sky(), rt, max_objects="live")
+        conn.update_buffers(size, scene, (0.0, 0.0))
+        if batched:
+            conn.draw_frames(jit, 0)
+        else:
+            for k in range(8):
+                conn.frame_data.jitter, conn.frame_data.progressive_count = (float(jit[k, 0]), float(jit[k, 1])), k
+                conn.draw()
+        device.sync()
+        st = device.stats()
+        results.append(crc(target.read_rgba8()))
+        if batched:
+            assert st.last_variant == 3 and st.last_stage >= 100 and st.last_batch == 8, "the launch did not spill its tail"
+    assert results[0] == results[1]
 
 
 def test_accumulation_converges_at_1080p(device):
