@@ -204,13 +204,14 @@ def test_pmc_summary_adds_the_two_render_kernels_of_a_launch(tmp_path):
 
 
 def test_committed_bench_line_keeps_the_contract():
-    """The JSON line bench.py printed on the GPU box (profiles/r03_bench_driver_flags.json, the driver's flags): every key
-    the bench contract names is there, with the types and relations it asks for; the counters it imports from a committed
+    """The JSON line bench.py printed on the GPU box (profiles/r04_bench_driver_flags.json, the driver's flags): every key
+    the bench contract names is there, with the types and relations it asks for; the roofline is the binding one (the FP32 vector
+    ALU), its fraction is only printed while it is one, the hardware's view stands next to it; the counters imported from a committed
     PMC profile name their source."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "r03_bench_driver_flags.json")) as f:
+    with open(os.path.join(root, "profiles", "r04_bench_driver_flags.json")) as f:
         d = json.loads([line for line in f if line.startswith("{")][-1])
     for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                       ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
@@ -220,8 +221,16 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["steps"] == 20 and d["warmup"] == 5 and d["n_gpus"] == 1 and d["higher_is_better"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"] is None or r["traffic"] > 0
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac_alg_reference_units_may_exceed_1"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["frac"] == r["frac_alg_reference_units_may_exceed_1"] and 0.0 < r["frac"] < 1.0   # printed as `frac` while it is a fraction
+    assert 0.3 < r["issue_util"] < 1.0 and "reference" in r["achieved_basis"] and "direction-mask table" in r["achieved_basis"]
+    assert r["traffic"] > 0
+    h = r["hbm"]
+    assert h["unit"] == "GB/s" and h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-4
+    assert "algorithmic" in h["achieved_basis"] and abs(h["measured_gbs"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+    # two launches in flight: the device time per launch (event span) is below one kernel pair's own duration
+    assert r["launches_in_flight"] == 2 and r["avg_launch_ms"] < r["kernel_avg_duration_ms"]
     # value = segments / time: consistent with ms_per_step and the segments per pixel the line reports
     px = 1920 * 1080
     # a step is one launch of config.frames_per_step frames (8 per GPU)
@@ -231,23 +240,41 @@ def test_committed_bench_line_keeps_the_contract():
     assert d["config"]["block_of_frames"]["frames_per_block"] == d["steps"]  # the protocol of rounds 1-2, still reported
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mrays/s" and c["sample"]
-    assert 0.0 < d["valu"]["frac"] < 1.0 and d["valu"]["peak"] == 157.3
+    assert c["host_cores"] >= c["cores"]
+    assert d["valu"]["frac"] == r["frac"] and d["valu"]["peak"] == 157.3   # (the alias older tools read)
     # imported, not measured in the run: says so, and from which kernel sources
     src = r["traffic_source"]
-    assert src["file"].startswith("profiles/traffic_r") and src["used"] is True and len(src["kernel_source_sha256"]) == 16
-    assert "algorithmic" in r["achieved_basis"] and abs(r["measured_gbs"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+    assert src["file"] == "profiles/traffic_r04.json" and src["used"] is True and len(src["kernel_source_sha256"]) == 16
     for leg in ("one_frame_per_launch", "reference_80_slots"):
         assert d["config"][leg]["mrays_per_s"] > 0
+    assert d["config"]["one_frame_per_launch"]["frames_per_block"] == 160   # the frames of a headline block, one per launch
+
+
+def test_a_reference_unit_fraction_above_one_is_never_printed_as_a_fraction():
+    """Config 3 (1 024 spheres): the launches test four of the 1 025 objects the reference's scan would, so F_alg / t is several
+    times the VALU peak — the line prints it under a key that says so, `frac` is null, `issue_util` carries the hardware's view."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r04_bench_config3.json")) as f:
+        d = json.loads([line for line in f if line.startswith("{")][-1])
+    r = d["roofline"]
+    assert "1024 spheres" in d["config"]["workload"] and r["bound"] == "valu"
+    assert r["frac"] is None and r["frac_alg_reference_units_may_exceed_1"] > 1.0 and d["valu"]["frac"] is None
+    assert 0.2 < r["issue_util"] < 1.0 and "candidate lists" in r["achieved_basis"]
+    assert r["traffic_source"]["file"] == "profiles/traffic_r04_config3.json" and r["traffic"] > r["hbm"]["alg_bytes_per_launch"] * 0.5
+    assert d["value"] >= 38000.0   # the round's target for this configuration
 
 
 def test_profile_counters_are_only_quoted_for_the_sources_they_were_measured_on():
-    """profiles/traffic_r03.json records the sha256 of the kernel sources it was collected on; bench.py quotes it only when
-    the tree still has those sources.  The committed profile must belong to the committed sources."""
+    """profiles/traffic_r04*.json record the sha256 of the kernel sources they were collected on; bench.py quotes them only when
+    the tree still has those sources.  The committed profiles must belong to the committed sources."""
     import json
     import os
     from rsraytracingv3_amd import _native
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "traffic_r03.json")) as f:
-        prof = json.load(f)
-    assert prof["kernel_source_sha256"] == _native.kernel_source_hash(), \
-        "csrc/ or include/ changed since the PMC profile was collected: re-run tools/profile_round.sh (bench.py now reports traffic null)"
+    for name in ("traffic_r04.json", "traffic_r04_config3.json"):
+        with open(os.path.join(root, "profiles", name)) as f:
+            prof = json.load(f)
+        assert prof["kernel_source_sha256"] == _native.kernel_source_hash(), \
+            "csrc/ changed since %s was collected: re-run tools/collect_round4.sh (bench.py now reports traffic null)" % name
