@@ -113,12 +113,13 @@ def main():
     ap.add_argument("--dirmask-k", type=int, default=0, help="RT_OPT_DIRMASK_K (0 = library default)")
     ap.add_argument("--dirmask-cells", type=int, default=0, help="RT_OPT_DIRMASK_CELLS (0 = library default)")
     ap.add_argument("--dirlist", type=int, default=-1, help="RT_OPT_DIRLIST: candidate lists of scenes with more than 128 spheres (0 = the sphere grid, 1 = library default)")
+    ap.add_argument("--dirlist-min", type=int, default=0, help="RT_OPT_DIRLIST_MIN: fewest spheres that get candidate lists (0 = library default 129)")
     ap.add_argument("--dirlist-k", type=int, default=0, help="RT_OPT_DIRLIST_K (0 = library default)")
     ap.add_argument("--dirlist-cells", type=int, default=0, help="RT_OPT_DIRLIST_CELLS (0 = library default)")
     ap.add_argument("--dirlist-reach", type=int, default=0, help="RT_OPT_DIRLIST_REACH (0 = library default)")
     ap.add_argument("--tail-spill", type=int, default=-1,
                     help="RT_OPT_TAIL_SPILL: workgroups with at most this many paths left hand them to the tail kernel (0 = off, -1 = library default)")
-    ap.add_argument("--tail-spill-single", type=int, default=-1, help="RT_OPT_TAIL_SPILL_SINGLE: the same for single-frame launches (-1 = library default 0)")
+    ap.add_argument("--tail-spill-single", type=int, default=-1, help="RT_OPT_TAIL_SPILL_SINGLE: the same for single-frame launches (-1 = library default 32)")
     ap.add_argument("--batch", type=int, default=0,
                     help="consecutive 1-spp frames per kernel launch (rt_render_frames, 1..64); 0 = 8 per GPU of the job, "
                          "so that a launch carries eight frames' worth of tiles whatever the partition")
@@ -191,6 +192,8 @@ def main():
         dev.set_option(N.RT_OPT_DIRMASK_CELLS, args.dirmask_cells)
     if args.dirlist >= 0:
         dev.set_option(N.RT_OPT_DIRLIST, args.dirlist)
+    if args.dirlist_min:
+        dev.set_option(N.RT_OPT_DIRLIST_MIN, args.dirlist_min)
     if args.dirlist_k:
         dev.set_option(N.RT_OPT_DIRLIST_K, args.dirlist_k)
     if args.dirlist_cells:
@@ -454,7 +457,7 @@ def main():
         prof_key = dict(prof.get("workload_key", {}))
         prof_key.pop("frames_per_launch", None)  # the profile's launches carried 8 frames; traffic is taken per frame
         tuned = (args.variant != -1 or args.dirmask >= 0 or args.dirmask_k or args.dirmask_cells or args.grid_min or args.flags or
-                 args.dirlist >= 0 or args.dirlist_k or args.dirlist_cells or args.dirlist_reach or
+                 args.dirlist >= 0 or args.dirlist_min or args.dirlist_k or args.dirlist_cells or args.dirlist_reach or
                  args.batch_inflight != 2 or args.blocks_per_cu or args.refill_min != 1 or args.tile_chunk != 2 or args.tail_spill >= 0 or args.tail_spill_single >= 0)
         if prof_key != workload_key or B <= 1 or tuned:  # the profile was collected with the library's defaults
             continue

@@ -366,8 +366,9 @@ enum {
   RT_OPT_DIRMASK_CELLS = 11,/* cells the table's grid aims at (default 4096; cubic cells, at most 64 per axis)           */
   RT_OPT_DIRMASK_K = 12,    /* direction bins per cube-map face edge, 1..16 (default 12: 864 bins)                       */
   RT_OPT_TAIL_SPILL_SINGLE = 14, /* the same threshold for single-frame launches in flight (rt_render with RT_OPT_INFLIGHT >= 2 and no
-                             * diagnostic outputs); default 0 = off: tail_stream costs a single frame ~35 us whatever it holds,
-                             * which only pays in long uninterrupted runs of frames (+1..2 %)                              */
+                             * diagnostic outputs) of 24 000 tiles or more (a whole 1080p frame); default 32 (0 = off): tail_stream costs a
+                             * single frame ~35 us whatever it holds, which pays in an uninterrupted loop of whole frames (+3.6 % at
+                             * 1080p and 8 bounces) and not for a rank's share of a frame or between synchronisations            */
   RT_OPT_TAIL_SPILL = 13,   /* multi-frame launches (rt_render_frames) of the re-packing shape, of 100 000 tiles or more (three
                              * 1080p frames) and two bounces or more, on a scene with a direction-mask table: a workgroup whose paths that hit number at most
                              * this many (0..128; -1 = the default: 32, 24 on a scene with candidate lists; 0 = off) hands them — path state + pending hit, 80 B — to a path

@@ -20,7 +20,8 @@ RT_OPT_INFLIGHT, RT_OPT_GRID_MIN, RT_OPT_BATCH_INFLIGHT = 6, 7, 8
 RT_OPT_DIRMASK, RT_OPT_DIRMASK_MIN, RT_OPT_DIRMASK_CELLS, RT_OPT_DIRMASK_K, RT_OPT_TAIL_SPILL = 9, 10, 11, 12, 13
 RT355_PRESENT_SLOTS = 4
 RT_TAIL_SPILL_DEFAULT = -1  # the default of the scene's kind (kDefaultTailSpill 32, kDefaultTailSpillLists 24: csrc/rt_device.h)
-RT_OPT_TAIL_SPILL_SINGLE = 14  # default 0
+RT_OPT_TAIL_SPILL_SINGLE = 14  # default 32 (single frames of 24 000 tiles or more and 7 bounces or more; 5 with candidate lists)
+RT_TAIL_SPILL_SINGLE_DEFAULT = 32
 RT_OPT_TIMING = 20
 RT_OPT_DIRLIST, RT_OPT_DIRLIST_MIN, RT_OPT_DIRLIST_CELLS, RT_OPT_DIRLIST_K, RT_OPT_DIRLIST_REACH = 15, 16, 17, 18, 19
 

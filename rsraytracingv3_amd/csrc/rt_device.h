@@ -85,9 +85,10 @@ constexpr int kDefaultGridMinSpheres = 129;    // RT_OPT_GRID_MIN
 constexpr int kDefaultInflight = 4;            // RT_OPT_INFLIGHT
 constexpr int kDefaultBatchInflight = 2;       // RT_OPT_BATCH_INFLIGHT: the next multi-frame launch renders while this one's tail drains and resolves
                                                // (round 3: 53.9 -> 57.8 Grays/s on the headline; one at a time: kernel times that do not overlap)
-constexpr int kDefaultTailSpillSingle = 0;     // RT_OPT_TAIL_SPILL_SINGLE: single frames in flight do not spill (A/B on one device, one frame per
-                                               // launch, threshold 0 / 32: 47.0 / 47.4 - 48.0 Grays/s in runs of 200 frames, 45.1 / 43.3 in runs of 20:
-                                               // tail_stream's fixed ~35 us per launch pay only in long uninterrupted runs)
+constexpr int kDefaultTailSpillSingle = 32;    // RT_OPT_TAIL_SPILL_SINGLE: single frames in flight of at least kTailMinTilesSingle tiles spill too.  Round 3 measured
+                                               // it in runs of 20 frames between two synchronisations (-4 %: tail_stream's fixed ~35 us per launch) and left it
+                                               // off; in an uninterrupted loop (blocks of 160 frames, A/B on one device, one frame per launch at 1080p) it is
+                                               // 47.4 -> 49.1 Grays/s at 8 bounces
 constexpr int kDefaultTailSpill = 32;          // RT_OPT_TAIL_SPILL (A/B on one device, thresholds 0 / 24 / 32 / 40: headline 50.3 / 52.9 / 52.9 /
                                                // 52.8 Grays/s, 80 slots 44.7 / 47.7 / 48.0 / 47.9, 3840x2160 54.2 / 58.5 / 58.9 / 58.9)
 
@@ -207,6 +208,12 @@ int stream_blocks_per_cu(size_t lds_bytes);
 // shape, the scene or the queue budget rule it out) and the records per queue shard it needs (five float4 planes of
 // kQueueShards shards); resident workgroups per CU of tail_stream.
 constexpr size_t kTailQueueBudget = 1ull << 30;  // bytes of queue a launch may ask for; the threshold shrinks to fit (8 frames of 4K at the default threshold: 1.33 GB -> 24)
+constexpr uint32_t kTailMinBouncesSingle = 7;    // ... and of at least this reflection limit: short paths leave too little tail to pay tail_stream's fixed cost (A/B on
+                                                 // one device, one frame per launch at 1080p, spill off / on by bounce limit 2 / 3 / 5 / 8: 58.3 / 54.1, 56.6 / 52.6,
+                                                 // 52.1 / 51.0, 47.4 / 48.8 Grays/s; 4K at 8: 48.7 / 51.4; the reference's 80 slots: 44.2 / 46.0)
+constexpr uint32_t kTailMinBouncesSingleLists = 5;  // ... on a scene with candidate lists (1 024 spheres, spill off / on at 3 / 4 / 5 / 8 bounces: 38.5 / 35.1, 36.1 / 34.6,
+                                                    // 33.1 / 34.0, 26.9 / 33.2; staged scenes at 6 / 7: 50.5 / 50.4, 48.8 / 49.5)
+constexpr uint64_t kTailMinTilesSingle = 24000;  // ... of a single-frame launch in flight (a whole 1080p frame is 32 400; a rank's share of one is not worth it)
 constexpr uint64_t kTailMinTiles = 100000;       // 8x8 tiles from which a launch spills (1080p: 2 frames per launch 42.8 Grays/s without /
                                                  // 41.0 with the spill, 4 frames 47.6 / 48.7, 8 frames 50.2 / 52.2: from three frames up)
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap);

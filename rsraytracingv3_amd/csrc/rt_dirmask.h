@@ -368,37 +368,57 @@ RT_HD bool dirlist_candidate(const DirListGeom &g, float4 reg, float &dmin) {
 RT_HD void dirlist_entry(const DirMaskParams &dm, uint32_t cell, uint32_t bin, const float4 *recs, const uint16_t *slot, uint32_t count,
                          uint32_t out[8]) {
   const DirListGeom g = dirlist_geometry(dm, cell, bin);
-  auto listed_within = [&](float reach) {  // candidates a ray can be accepted by within `reach`
-    uint32_t c = 0;
-    for (uint32_t j = 0; j < count; ++j) {
-      float dmin;
-      if (dirlist_candidate(g, recs[j], dmin) && dmin <= reach) c += 1u;
-    }
-    return c;
+  const float reach_max = dm.reach_unit * static_cast<float>(kDirListReachQuanta);
+  auto put = [&](uint32_t n, uint32_t j) {  // slot number n of the entry = sphere j of the list
+    const uint32_t s = slot ? static_cast<uint32_t>(slot[j]) : j;
+    const uint32_t hw = 1u + n;  // half-word index
+    out[hw >> 1] |= s << (16u * (hw & 1u));
   };
-  uint32_t q = kDirListReachQuanta;
-  if (listed_within(dm.reach_unit * static_cast<float>(q)) > kDirListSlots) {
-    // the largest reach that lists at most 15: bisection over the quanta (q = 0: none does — the entry serves no ray)
-    uint32_t lo = 0u, hi = q;  // count(hi) > 15; lo = 0 stands for "unserved"
-    while (hi - lo > 1u) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (listed_within(dm.reach_unit * static_cast<float>(mid)) <= kDirListSlots) lo = mid;
-      else hi = mid;
+  for (int w = 0; w < 8; ++w) out[w] = 0u;
+  // One pass serves most entries: the candidates within the largest reach are written as they are found, up to 15.
+  uint32_t n = 0;
+  bool more = false;
+  for (uint32_t j = 0; j < count; ++j) {
+    float dmin;
+    if (dirlist_candidate(g, recs[j], dmin) && dmin <= reach_max) {
+      if (n < kDirListSlots) put(n++, j);
+      else more = true;
     }
-    q = lo;
+  }
+  if (!more) {
+    out[0] |= (n << 12) | kDirListReachQuanta;
+    return;
+  }
+  // More than 15: the entry's reach is cut to the largest quantum count q with at most 15 candidates within q * reach_unit — i.e. with
+  // q * reach_unit below the 16th smallest lower bound, found by a second pass that keeps the 16 smallest (q = 0: even the 16th
+  // is 0 — more than 15 registered balls overlap the cell —: the entry serves no ray).
+  float best[kDirListSlots + 1u];
+  for (uint32_t k = 0; k <= kDirListSlots; ++k) best[k] = INFINITY;
+  for (uint32_t j = 0; j < count; ++j) {
+    float dmin;
+    if (dirlist_candidate(g, recs[j], dmin) && dmin <= reach_max && dmin < best[kDirListSlots]) {
+      uint32_t k = kDirListSlots;
+      while (k > 0u && best[k - 1u] > dmin) {
+        best[k] = best[k - 1u];
+        k -= 1u;
+      }
+      best[k] = dmin;
+    }
+  }
+  const float d16 = best[kDirListSlots];
+  uint32_t q = 0u;
+  if (d16 > 0.0f) {
+    const float fq = floorf(d16 / dm.reach_unit);
+    q = fq >= static_cast<float>(kDirListReachQuanta) ? kDirListReachQuanta : static_cast<uint32_t>(fq);
+    while (q > 0u && !(dm.reach_unit * static_cast<float>(q) < d16)) q -= 1u;  // (the product as the kernels and the pass below form it)
   }
   for (int w = 0; w < 8; ++w) out[w] = 0u;
   if (q == 0u) return;  // n = 0, q = 0
   const float reach = dm.reach_unit * static_cast<float>(q);
-  uint32_t n = 0;
+  n = 0;
   for (uint32_t j = 0; j < count; ++j) {
     float dmin;
-    if (dirlist_candidate(g, recs[j], dmin) && dmin <= reach) {
-      const uint32_t s = slot ? static_cast<uint32_t>(slot[j]) : j;
-      const uint32_t hw = 1u + n;  // half-word index
-      out[hw >> 1] |= s << (16u * (hw & 1u));
-      n += 1u;
-    }
+    if (dirlist_candidate(g, recs[j], dmin) && dmin <= reach && n < kDirListSlots) put(n++, j);
   }
   out[0] |= (n << 12) | q;
 }

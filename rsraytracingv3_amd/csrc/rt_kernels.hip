@@ -76,6 +76,9 @@ namespace {
 #ifndef RT_LAZY_OBJ
 #define RT_LAZY_OBJ 1     // sample-only kernels of large scenes: a sphere hit's object index is fetched only to break a distance tie with a plane
 #endif
+#ifndef RT_BLOCKS_WAVES_SINGLE_LISTS
+#define RT_BLOCKS_WAVES_SINGLE_LISTS 6  // ... their sample-only single-frame launches
+#endif
 #ifndef RT_BLOCKS_WAVES_SINGLE
 #define RT_BLOCKS_WAVES_SINGLE 5  // ... in sample-only single-frame launches, several of which are in flight (register count held at the
                                   // 5-wave step).  5 / 6 / 7 waves, one frame per launch at 8 bounces: 47.2 / 44.8 / 46.3 Grays/s before the
@@ -2714,32 +2717,32 @@ int launch_render(const DeviceScene &sc, const FrameParams &fp, const LaunchConf
     const bool lean = sample_only(fp);
     const bool spill = lean && fp.spill_max != 0u && fp.queue != nullptr;
     const dim3 threads(nw * 64);
-#define RT_LAUNCH_BLOCKS(WAVES, LEAN_, SPILL_)                                                                                            \
-  do {                                                                                                                                    \
-    if (lists) hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW_LISTS, WAVES, LEAN_, SPILL_, true>), blocks, threads, bytes, stream, sc, fp); \
-    else hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, WAVES, LEAN_, SPILL_, false>), blocks, threads, bytes, stream, sc, fp);           \
+#define RT_LAUNCH_BLOCKS(WAVES, WAVES_LISTS, LEAN_, SPILL_)                                                                                     \
+  do {                                                                                                                                         \
+    if (lists) hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW_LISTS, WAVES_LISTS, LEAN_, SPILL_, true>), blocks, threads, bytes, stream, sc, fp); \
+    else hipLaunchKernelGGL((render_blocks<RT_BLOCK_NW, WAVES, LEAN_, SPILL_, false>), blocks, threads, bytes, stream, sc, fp);                \
   } while (0)
     if (fp.batch > 1u && lean) {
       if (lists) {
         if (stage_used) *stage_used = 10 * RT_BLOCK_NW_LISTS + RT_BLOCKS_WAVES_LISTS;
-        if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_LISTS, true, true);
-        else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_LISTS, true, false);
+        if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH, RT_BLOCKS_WAVES_LISTS, true, true);
+        else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH, RT_BLOCKS_WAVES_LISTS, true, false);
       } else if (sc.dm.enabled && sc.dm.words > 1u) {
         if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH_WIDE;
-        if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH_WIDE, true, true);
-        else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH_WIDE, true, false);
+        if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH_WIDE, RT_BLOCKS_WAVES_LISTS, true, true);
+        else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH_WIDE, RT_BLOCKS_WAVES_LISTS, true, false);
       } else {
         if (stage_used) *stage_used = 10 * RT_BLOCK_NW + RT_BLOCKS_WAVES_BATCH;
-        if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH, true, true);
-        else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH, true, false);
+        if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH, RT_BLOCKS_WAVES_LISTS, true, true);
+        else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_BATCH, RT_BLOCKS_WAVES_LISTS, true, false);
       }
     } else if (lean) {
-      if (stage_used) *stage_used = 10 * static_cast<int>(nw) + RT_BLOCKS_WAVES_SINGLE;
-      if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_SINGLE, true, true);
-      else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_SINGLE, true, false);
+      if (stage_used) *stage_used = 10 * static_cast<int>(nw) + (lists ? RT_BLOCKS_WAVES_SINGLE_LISTS : RT_BLOCKS_WAVES_SINGLE);
+      if (spill) RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_SINGLE, RT_BLOCKS_WAVES_SINGLE_LISTS, true, true);
+      else RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_SINGLE, RT_BLOCKS_WAVES_SINGLE_LISTS, true, false);
     } else {
       if (stage_used) *stage_used = 10 * static_cast<int>(nw) + RT_BLOCKS_WAVES_FULL;
-      RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_FULL, false, false);
+      RT_LAUNCH_BLOCKS(RT_BLOCKS_WAVES_FULL, RT_BLOCKS_WAVES_FULL, false, false);
     }
 #undef RT_LAUNCH_BLOCKS
     if (spill) {  // the spilled paths' remaining bounces, in full waves
@@ -2824,7 +2827,10 @@ uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const Lau
   if (wanted == 0u || !sample_only(fp) || !sc.dm.enabled || pick_variant(sc, fp, lc) != 3) return 0u;
   // nothing to hand over when the first shading is the last; and tail_stream costs a launch ~35 us whatever it holds, which
   // small launches do not earn back (RT_OPT_FLAGS bit 2 lifts the size rule: tests)
-  if (fp.reflection_limit < 2u || (launch_tiles(fp) < kTailMinTiles && !(lc.flags & 4))) return 0u;
+  const uint64_t min_tiles = fp.batch > 1u ? kTailMinTiles : kTailMinTilesSingle;
+  if (fp.batch == 1u && !(lc.flags & 4) && fp.reflection_limit < ((sc.dm.enabled && sc.dm.lists) ? kTailMinBouncesSingleLists : kTailMinBouncesSingle))
+    return 0u;
+  if (fp.reflection_limit < 2u || (launch_tiles(fp) < min_tiles && !(lc.flags & 4))) return 0u;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile, tiles_y = (fp.local_rows + kTile - 1) / kTile;
   const uint32_t nw = (sc.dm.enabled && sc.dm.lists) ? RT_BLOCK_NW_LISTS : RT_BLOCK_NW;
   const uint64_t blocks = static_cast<uint64_t>((tiles_x + nw - 1) / nw) * tiles_y * fp.batch;  // render_blocks' grid

@@ -850,6 +850,13 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
     const int drc = build_dirmask(ctx, sph.data(), static_cast<uint32_t>(n_sph_live));
     if (drc != RT_OK) return drc;
   }
+  if (!ctx->scene.dm.enabled && ctx->d_dirmask && ctx->dirmask_cap * sizeof(unsigned long long) > (64ull << 20)) {
+    // a large table (candidate lists take hundreds of megabytes) of a scene that is gone, and this one uses none: give the memory back
+    (void)hipFree(ctx->d_dirmask);
+    ctx->d_dirmask = nullptr;
+    ctx->dirmask_cap = 0;
+    ctx->dirmask_built_for.clear();
+  }
   ctx->have_scene = true;
   ctx->masks_dirty = true;
   ctx->stats.object_count = object_count;

@@ -455,7 +455,7 @@ def test_tail_spill_hands_the_last_paths_to_full_waves(device, case):
     finally:
         device.set_option(N.RT_OPT_FLAGS, 0)
         device.set_option(N.RT_OPT_TAIL_SPILL, N.RT_TAIL_SPILL_DEFAULT)
-        device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, 0)
+        device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, N.RT_TAIL_SPILL_SINGLE_DEFAULT)
         device.set_option(N.RT_OPT_REFILL_MIN, 1)
         device.set_option(N.RT_OPT_TILE_CHUNK, 2)
         device.set_partition(0, 1, 8)
@@ -897,6 +897,6 @@ def test_candidate_lists_in_multi_frame_launches_with_a_tail_spill(device, spher
     finally:
         device.set_option(N.RT_OPT_FLAGS, 0)
         device.set_option(N.RT_OPT_TAIL_SPILL, N.RT_TAIL_SPILL_DEFAULT)
-        device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, 0)
+        device.set_option(N.RT_OPT_TAIL_SPILL_SINGLE, N.RT_TAIL_SPILL_SINGLE_DEFAULT)
         device.set_option(N.RT_OPT_REFILL_MIN, 1)
         device.set_option(N.RT_OPT_TILE_CHUNK, 2)
