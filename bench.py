@@ -20,10 +20,14 @@ MAX over ranks — is repeated until >= 1 s has been measured and the MEDIAN blo
 one-frame-per-launch leg (the reference's call pattern: one draw per loop turn; there a step is one frame) and the
 reference-exact 80-slot leg (15 zero-padded objects scanned as the reference's shader does).
 
-`roofline` prices the render kernel's ALGORITHMIC bytes (8 B/pixel + 16 B/segment +
-8 B/rough hit) against the 8 TB/s HBM peak, from per-launch HIP-event durations taken on the context's stream
-inside the timed region; `valu` prices the algorithmic flops against the 157.3 TFLOP/s FP32 vector peak (the
-bound that binds — DESIGN.md §5).  `cpu_baseline` is the CPU oracle (OpenMP) on the same frames, reported,
+`roofline` is the bound that binds: `bound` "valu" — the render kernels' ALGORITHMIC flops (25 per
+object a segment would test in the reference's scan + 200 per segment + 60 per pixel) against the 157.3 TFLOP/s
+FP32 vector peak, from per-launch HIP-event durations taken on the context's stream inside the timed region.  That
+fraction is in the reference's units: the candidate tables skip most of the scan it prices, so it can exceed 1
+(`frac` is null then, the labelled field keeps the figure); `issue_util` is the hardware's own fraction (vector
+instructions x 2 cycles over the SIMDs' busy cycles), imported with `traffic` from the PMC profile of the same
+sources under profiles/.  `roofline.hbm` keeps the HBM pricing (8 B/pixel + 16 B/segment + 8 B/rough hit against
+8 TB/s).  `cpu_baseline` is the CPU oracle (OpenMP) on the same frames, reported,
 not targeted.
 """
 import argparse

@@ -620,7 +620,7 @@ def test_intermediate_frames_of_a_batch_launch(device, accum):
 
 @pytest.mark.parametrize("accum", [N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32])
 def test_multi_frame_launches_in_flight_equal_one_at_a_time(device, accum):
-    """RT_OPT_BATCH_INFLIGHT (default 1; here 3, 2 and 1) with RT_OPT_INFLIGHT 4 / 2 / 1: a mixed sequence of multi-frame
+    """RT_OPT_BATCH_INFLIGHT (default 2; here 3, 2 and 1) with RT_OPT_INFLIGHT 4 / 2 / 1: a mixed sequence of multi-frame
     launches and single frames, queued without a sync, the random texture replaced on the device in between — launches
     overlap on the internal streams, the history is folded strictly in frame order, so texels and floats equal those of
     one launch at a time.  rt_get_launch_span: the device time of overlapping launches is less than the sum of their
