@@ -1571,6 +1571,40 @@ __device__ __forceinline__ TilePos grid_tile_pos() {
   return t;
 }
 
+// The same for render_blocks, XCD-aware in launches of several frames (`banded`).  Workgroups go to the eight XCDs in turn (linear
+// workgroup id % 8), so with the plain map an XCD renders every eighth 16-pixel column of the whole frame and its L2 — 4 MB — sees the
+// whole candidate table (32 MB at the headline scene, 456 MB at 1 024 spheres).  Here XCD k's run of workgroups walks ONE vertical band of
+// the frame (an eighth of its width) row by row: what an XCD has in flight at a time is a compact 240 x 240 pixel square of a 1080p image,
+// whose secondary rays start in a few cells of the table.  The bands rotate over the XCDs every 2^RT_XCD_BAND_ROWS_LOG2 tile rows and
+// every frame, so that each XCD gets its share of sky and of spheres.  A/B on one device (profiles/r04_ab_xcd_bands.txt), 8 frames per
+// launch: headline +1.3 %, 3840x2160 +2.4 %, 1 024 spheres +2.8 %; rotation every 2 / 4 / 8 / 16 / 32 / 64 rows 57.3 / 57.5 / 57.6 /
+// 57.8 / 57.9 / 57.7 Grays/s.  Single frames LOSE (-1 % at 2 rows ... -9 % at 32, -20 % at 64: one frame gives an XCD four and a half squares,
+// not enough to even out) and keep the plain map; so does a launch whose XCDs take a tile position in all its frames before they move on
+// (frames innermost, no rotation over the frames: -0.5 % ... -11 % against this map by rotation period).  Needs a grid width that is a multiple of 8 (1920 and 3840 pixels are); others: plain.
+#ifndef RT_XCD_BANDS
+#define RT_XCD_BANDS 1
+#endif
+#ifndef RT_XCD_BAND_ROWS_LOG2
+#define RT_XCD_BAND_ROWS_LOG2 5
+#endif
+template <int WAVES_PER_BLOCK>
+__device__ __forceinline__ TilePos block_tile_pos(bool banded) {
+  uint32_t bx = blockIdx.x, by = blockIdx.y;
+  if (RT_XCD_BANDS && banded && (gridDim.x & 7u) == 0u) {
+    const uint32_t l = blockIdx.y * gridDim.x + blockIdx.x;  // (a frame's workgroups are a multiple of 8: the next frame starts on XCD 0 again)
+    const uint32_t k = l & 7u, i = l >> 3;
+    const uint32_t bw = gridDim.x >> 3;
+    by = i / bw;
+    const uint32_t band = (k + (by >> RT_XCD_BAND_ROWS_LOG2) + blockIdx.z) & 7u;
+    bx = band * bw + (i - by * bw);
+  }
+  TilePos t;
+  t.col = bx * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  t.row = by;
+  t.frame = blockIdx.z;
+  return t;
+}
+
 // STAGE: 2 = the whole scene image staged into LDS, 1 = only the sphere records (scenes of hundreds of
 // spheres), 3 = the sphere records and the sphere grid (secondary rays walk the grid), 0 = nothing (scenes
 // beyond a workgroup's LDS): everything else is read from global memory; 4 = nothing staged, secondary rays use the candidate
@@ -1664,7 +1698,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-  const TilePos tp = grid_tile_pos<NW>();
+  const TilePos tp = block_tile_pos<NW>(fp.batch > 1u);
   const uint32_t x = tp.col * kTile + (lane & 7u);
   const uint32_t lrow = tp.row * kTile + (lane >> 3);
   Path s;

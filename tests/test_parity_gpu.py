@@ -376,6 +376,21 @@ def test_batch_launch_equals_sequential_frames(device, variant, accum):
     assert np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32))
 
 
+@pytest.mark.parametrize("case", ["headline_live", "stress_300"])
+def test_xcd_band_map_of_multi_frame_launches(device, case):
+    """render_blocks deals the tiles of a multi-frame launch to the XCDs in vertical bands (block_tile_pos) when its grid is a multiple
+    of 8 workgroups wide — 128 pixels: 8 two-wave workgroups, 16 one-wave ones with candidate lists — and rotates the bands every 32 tile
+    rows and every frame: 42 tile rows (the last one ragged) x 3 frames in ONE launch == the same frames one launch each (plain map), bit for
+    bit, and every pixel-frame rendered exactly once (the launch's pixel count)."""
+    scene = cases.headline_scene(6) if case == "headline_live" else cases.stress_scene(300, 6)
+    sky, rnd = cases.inputs(256, 128)
+    jit = [(0.1, -0.2), (-0.33, 0.27), (0.45, 0.05)]
+    (seq, bat), st = _batch_vs_sequential(device, scene, (128, 330), sky, rnd, jit, 2, N.RT_ACCUM_SRGB8, 3)
+    assert st.last_variant == 3 and st.last_batch == 3 and st.last_pixels == 3 * 128 * 330
+    assert np.array_equal(seq[0], bat[0])
+    assert np.array_equal(seq[1].view(np.uint32), bat[1].view(np.uint32))
+
+
 @pytest.mark.parametrize("refill_min,tile_chunk", [(1, 1), (1, 2), (9, 3), (64, 1)])
 def test_streamed_shape_primary_pass_queue_bounce_pass(device, refill_min, tile_chunk):
     """Variant 4 (primary pass -> path queue -> resident waves refilled from the queue) in a multi-frame launch: the
