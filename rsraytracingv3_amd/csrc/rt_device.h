@@ -56,7 +56,7 @@ struct GridParams {
 struct DeviceScene {
   const float4 *image;
   GridParams grid;
-  DirMaskParams dm;        // candidate-sphere masks for secondary rays (rt_dirmask.h); scenes of up to 64 spheres
+  DirMaskParams dm;        // candidate-sphere masks for secondary rays (rt_dirmask.h): bit sets up to 128 spheres, candidate lists beyond
   uint32_t n_sph, n_pl, n_obj;
   uint32_t n_sph_pad;      // records in sph[]: n_sph rounded up to kSphBatch, plus one batch of read-ahead
   uint32_t image_records;  // float4 records in the whole image
@@ -159,6 +159,9 @@ struct FrameParams {
   // ends; tail_stream shades and continues them in full waves.  0 = off.  A workgroup spills once, so a shard of
   // ceil(workgroups / kQueueShards) * spill_max records cannot overflow (tail_spill_plan).
   uint32_t spill_max;
+  // render_blocks' workgroup -> tile map (block_tile_pos in rt_kernels.hip): 0 = plain; otherwise 1 + the number of bands the
+  // rotation starts at — the launch's number, so that consecutive launches give an XCD different bands of the frame
+  uint32_t xcd_bands;
 };
 
 // resolve_batch_kernel: folds a batch's float samples into the history, frame by frame

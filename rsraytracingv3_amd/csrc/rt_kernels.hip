@@ -1588,14 +1588,14 @@ __device__ __forceinline__ TilePos grid_tile_pos() {
 #define RT_XCD_BAND_ROWS_LOG2 5
 #endif
 template <int WAVES_PER_BLOCK>
-__device__ __forceinline__ TilePos block_tile_pos(bool banded) {
+__device__ __forceinline__ TilePos block_tile_pos(uint32_t xcd_bands) {
   uint32_t bx = blockIdx.x, by = blockIdx.y;
-  if (RT_XCD_BANDS && banded && (gridDim.x & 7u) == 0u) {
+  if (RT_XCD_BANDS && xcd_bands != 0u && (gridDim.x & 7u) == 0u) {
     const uint32_t l = blockIdx.y * gridDim.x + blockIdx.x;  // (a frame's workgroups are a multiple of 8: the next frame starts on XCD 0 again)
     const uint32_t k = l & 7u, i = l >> 3;
     const uint32_t bw = gridDim.x >> 3;
     by = i / bw;
-    const uint32_t band = (k + (by >> RT_XCD_BAND_ROWS_LOG2) + blockIdx.z) & 7u;
+    const uint32_t band = (k + (by >> RT_XCD_BAND_ROWS_LOG2) + blockIdx.z + xcd_bands - 1u) & 7u;
     bx = band * bw + (i - by * bw);
   }
   TilePos t;
@@ -1698,7 +1698,7 @@ __global__ void __launch_bounds__(NW * 64, WAVES) render_blocks(DeviceScene sc, 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   const uint32_t tiles_x = (fp.width + kTile - 1) / kTile;
-  const TilePos tp = block_tile_pos<NW>(fp.batch > 1u);
+  const TilePos tp = block_tile_pos<NW>(fp.xcd_bands);
   const uint32_t x = tp.col * kTile + (lane & 7u);
   const uint32_t lrow = tp.row * kTile + (lane >> 3);
   Path s;

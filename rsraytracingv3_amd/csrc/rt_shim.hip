@@ -190,6 +190,7 @@ struct rt_context {
   bool present_queued[kPresentSlots] = {};             // a copy into the slot has been queued (and not been waited for since)
   uint32_t *d_present[kPresentSlots] = {};             // device-side snapshot of the frame the slot's copy reads: the target itself is
   size_t present_dev_cap[kPresentSlots] = {};          // the history, which the next launch overwrites in place
+  uint32_t launch_seq = 0;                             // launches so far (FrameParams::xcd_bands)
   int present_guard = -1;                              // (unused since the snapshots: kept -1)
   rt_stats stats{};
   std::string error;
@@ -1264,6 +1265,10 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   fp.progressive_count = progressive_count;
   fp.batch = batch;
   fp.frame_tile_rows = (ctx->local_rows + 7u) / 8u;
+#ifndef RT_XCD_BANDS_SINGLE
+#define RT_XCD_BANDS_SINGLE 0
+#endif
+  fp.xcd_bands = (batch > 1u || RT_XCD_BANDS_SINGLE) ? 1u + (ctx->launch_seq++ & 7u) : 0u;
   bool jitter_small = true;
   for (uint32_t f = 0; f < batch; ++f) {
     fp.jitter[2 * f] = jitter[2 * f];
