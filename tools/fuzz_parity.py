@@ -42,6 +42,8 @@ def random_case(seed):
                  float(rs.choice([1.0, 20.0, 70.0, 90.0])))
     scene = Scene(objects=objs, camera=cam, reflection_limit=int(rs.choice([1, 2, 3, 8, 20])))
     size = (int(rs.randint(1, 200)), int(rs.randint(1, 120)))
+    if rs.randint(0, 6) == 0:  # a grid of 8 or 16 workgroups across: multi-frame launches of render_blocks use the XCD band map
+        size = (int(rs.choice([121, 128, 249, 256])), int(rs.randint(1, 300)))
     jitter = (float(rs.uniform(-0.495, 0.495)), float(rs.uniform(-0.495, 0.495)))
     slots = "live" if (len(objs) > 80 or rs.rand() < 0.5) else None
     return scene, size, jitter, slots, int(rs.choice([-1, 0, 1, 2, 3])), int(rs.randint(1, 1000))
