@@ -86,6 +86,9 @@ typedef struct rt_stats {
                                  a launch that spills allocates what it needs, at most 1 GiB)                              */
   uint32_t dirmask_lists;     /* 0: the table holds bit sets (scenes of up to 128 spheres); otherwise it holds candidate lists
                                  (larger scenes) and this is the largest reach of an entry, in cells                    */
+  uint32_t spheres_scanned;   /* sphere records the kernels hold: sphere_count minus the records that repeat an earlier one bit for
+                                 bit (the zero-filled tail of the reference's 80-slot buffer: 15 -> 1), which can never win
+                                 against their first occurrence (ray.hlsl:98-106: strict '<', ascending order)              */
 } rt_stats;
 
 /* Device-side view of the context's buffers, for zero-copy consumers (RCCL gather,
@@ -342,7 +345,8 @@ enum {
   RT_OPT_TILE_CHUNK = 3,   /* variant 2: consecutive 8x8 tiles a wave takes per work-counter bump; variant 4: 64-path
                               units a wave takes off the path queue at a time */
   RT_OPT_FLAGS = 4,        /* experiment switches: bit 1 (2) ignore the sphere grid; bit 2 (4) launches of every size spill their
-                              tail (RT_OPT_TAIL_SPILL) — speed only, frames stay bit-identical; bit 4 (16) DRY launches: every
+                              tail (RT_OPT_TAIL_SPILL) — speed only, frames stay bit-identical; bit 3 (8) rt_set_scene keeps sphere records that repeat an
+                              earlier one (rt_stats.spheres_scanned) — speed only; bit 4 (16) DRY launches: every
                               kernel of a launch (render, tail, resolve, assembly) runs ONE workgroup and peer copies move one row —
                               all of a frame's host calls, events and stream waits with next to none of its device work, to tell
                               host time from device time (tools/multi_times.py); the frames are garbage                         */

@@ -494,10 +494,13 @@ __device__ __forceinline__ SphereHit scan_spheres_listed(const float4 *__restric
                                                          const unsigned long long *__restrict__ row_mask, uint32_t words) {
   uint32_t best_key = kNoHitKey;
   int slot = -1;
+  // Both words of a two-word mask (65..128 spheres: the reference's 80 slots) are requested before the first one is walked: read
+  // inside the loop, the second word's loads would start when the first word's spheres are done — one more memory round trip per tile.
+  unsigned long long m_next = (words > 1u) ? (col_mask[1] & row_mask[1]) : 0ull;
   for (uint32_t w = 0; w < words; ++w) {
     // a tile's spheres = those inside its column slab AND its row slab; the addresses are the same
     // in every lane: read once, keep in SGPRs
-    unsigned long long m = col_mask[w] & row_mask[w];
+    unsigned long long m = (w == 0u) ? (col_mask[0] & row_mask[0]) : (w == 1u ? m_next : (col_mask[w] & row_mask[w]));
     m = (static_cast<unsigned long long>(__builtin_amdgcn_readfirstlane(static_cast<int>(m >> 32))) << 32) |
         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(m)));
     RT_CNT(3, __popcll(m))

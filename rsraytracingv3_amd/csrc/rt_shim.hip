@@ -19,6 +19,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/rt355.h"
@@ -765,6 +766,26 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   const auto *wire = static_cast<const uint8_t *>(objects);
   std::vector<float4> sph, smat0, smat1, pl_a, pl_b, pmat0, pmat1;
   std::vector<int> sph_obj;
+  // Sphere records that repeat an earlier one bit for bit — the reference's buffer is 80 slots with a zero-filled tail (scene.rs:28,
+  // bytes.rs:73-80): 15 spheres of radius 0 at the origin behind a scene of 64 — are left out of the image: the same arithmetic on the
+  // same record gives the same distance, and the scan replaces its closest hit only by a strictly smaller one (ray.hlsl:98-106), in
+  // ascending object order, so a repeat can never win against its first occurrence, whatever its material.  (Fifteen coincident
+  // registered balls in the middle of the scene otherwise sit in the candidate set of every ray that passes the origin.)
+  // RT_OPT_FLAGS bit 3 keeps them (A/B, tests).
+  const bool drop_repeats = !(ctx->flags & 8);
+  struct RecordKey {
+    uint32_t w[4];
+    bool operator==(const RecordKey &o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+  };
+  struct RecordHash {
+    size_t operator()(const RecordKey &k) const {
+      uint64_t h = 0x9e3779b97f4a7c15ull;
+      for (uint32_t v : k.w) h = (h ^ v) * 0xff51afd7ed558ccdull + (h >> 29);
+      return static_cast<size_t>(h);
+    }
+  };
+  std::unordered_set<RecordKey, RecordHash> seen;
+  uint32_t wire_spheres = 0;
   for (uint32_t i = 0; i < object_count; ++i) {
     rt_wire_object o;
     std::memcpy(&o, wire + static_cast<size_t>(i) * RT355_OBJECT_STRIDE, sizeof o);
@@ -778,7 +799,12 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
     const float4 m1 = make_float4(o.emission[0] * o.emission_strength, o.emission[1] * o.emission_strength,
                                   o.emission[2] * o.emission_strength, inv_exp);
     if (o.option == 0u) {  // ray.hlsl:53-68
-      sph.push_back(make_float4(o.center[0], o.center[1], o.center[2], o.f32_data * o.f32_data));
+      wire_spheres += 1u;
+      const float4 rec = make_float4(o.center[0], o.center[1], o.center[2], o.f32_data * o.f32_data);
+      RecordKey key;
+      std::memcpy(key.w, &rec, sizeof key.w);
+      if (drop_repeats && !seen.insert(key).second) continue;
+      sph.push_back(rec);
       sph_obj.push_back(static_cast<int>(i));
       smat0.push_back(m0);
       smat1.push_back(m1);
@@ -861,7 +887,8 @@ int rt_set_scene(rt_context *ctx, const void *objects, uint32_t object_count, co
   ctx->have_scene = true;
   ctx->masks_dirty = true;
   ctx->stats.object_count = object_count;
-  ctx->stats.sphere_count = ctx->scene.n_sph;
+  ctx->stats.sphere_count = wire_spheres;
+  ctx->stats.spheres_scanned = ctx->scene.n_sph;
   ctx->stats.plane_count = ctx->scene.n_pl;
   return RT_OK;
 }

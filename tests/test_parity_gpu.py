@@ -764,6 +764,38 @@ def test_degenerate_spheres_around_ray_origins(device, variant):
         assert st.last_segments == int(ref.segments.sum())
 
 
+@pytest.mark.parametrize("variant", [0, 3])
+def test_repeated_sphere_records_are_dropped_and_the_first_one_wins(device, variant):
+    """rt_set_scene leaves sphere records that repeat an earlier one bit for bit out of the scene image (the zero-filled tail of the
+    reference's 80 slots: 15 -> 1).  The scan's strict '<' in ascending object order (ray.hlsl:98-106) lets the FIRST occurrence win
+    whatever the materials: copies of three spheres of the headline scene with other materials, spread over the buffer, plus the zero
+    tail — frame, segment counts and hit indices are the oracle's (it scans all 80), with the copies dropped and (RT_OPT_FLAGS bit 3)
+    with them kept."""
+    import copy
+    from rsraytracingv3_amd.scene import Material, Object
+    scene = cases.headline_scene(6)
+    scene.objects = scene.objects[:40] + [scene.objects[-1]]  # 40 spheres + the ground plane
+    spheres = [o for o in scene.objects if o.geometry.kind == 0]
+    for k, src in enumerate((spheres[3], spheres[17], spheres[3], spheres[30])):
+        twin = Object("twin%d" % k, Material((0.1, 0.9, 0.2), (1.0, 0.0, 1.0), 5.0, 0.5, 0.9 if k % 2 else 0.0), copy.deepcopy(src.geometry))
+        scene.objects.insert(7 * k + 5, twin) if k < 2 else scene.objects.append(twin)
+    n_wire = sum(1 for o in scene.objects if o.geometry.kind == 0)
+    sky, rnd = cases.inputs(128, 64)
+    size, jitter = (160, 96), (0.2, -0.3)
+    ref = run_oracle(scene, size, sky, rnd, jitter)  # the reference's 80 slots
+    for keep in (0, 8):
+        device.set_option(N.RT_OPT_FLAGS, keep)
+        try:
+            outs, st = run_gpu(device, scene, size, sky, rnd, jitter, variant=variant)
+        finally:
+            device.set_option(N.RT_OPT_FLAGS, 0)
+        assert_frame_equal(outs[0], ref)
+        zero_tail = 80 - len(scene.objects)
+        assert st.sphere_count == n_wire + zero_tail
+        # dropped: the two copies behind their originals count; a copy placed BEFORE its original makes the original the repeat
+        assert st.spheres_scanned == (st.sphere_count if keep else n_wire - 4 + 1)
+
+
 @pytest.mark.parametrize("variant", [0, 2, 3])
 @pytest.mark.parametrize("case", ["headline_live", "reference_80_slots", "stress_100", "stress_128", "inside_the_scene"])
 def test_direction_mask_table_never_changes_a_frame(device, variant, case):

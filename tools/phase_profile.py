@@ -31,6 +31,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--spheres", type=int, default=64)
 ap.add_argument("--tail-spill", type=int, default=-1, help="RT_OPT_TAIL_SPILL (tail_stream's stamps: 5 refill, 3 shading, 1 scan, 6 misses)")
 ap.add_argument("--refill-min", type=int, default=1)
+ap.add_argument("--slots", type=int, default=0, help="80: the reference's buffer with its zero-filled tail instead of the live objects")
 args = ap.parse_args()
 W, H = args.width, args.height
 scene = cases.headline_scene(8) if args.spheres == 64 else cases.stress_scene(args.spheres, 8)
@@ -45,7 +46,7 @@ dev.set_option(N.RT_OPT_REFILL_MIN, args.refill_min)
 target = RenderTarget.new(dev, (W, H))
 rt = RandomTexture(dev)
 rt.write(synth.random_texture(1))
-conn = Connection(scene, dev, synth.procedural_skybox(2048, 1024), rt, max_objects="live")
+conn = Connection(scene, dev, synth.procedural_skybox(2048, 1024), rt, max_objects=(args.slots if args.slots else "live"))
 conn.update_buffers((W, H), scene, (0.0, 0.0))
 jit = synth.jitter_sequence(42, 4096)
 k = 0
