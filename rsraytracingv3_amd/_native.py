@@ -56,7 +56,8 @@ class RtGridInfo(C.Structure):
 class RtDirMaskInfo(C.Structure):
     _fields_ = [("enabled", C.c_uint32), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32), ("k", C.c_uint32),
                 ("bins", C.c_uint32), ("words", C.c_uint32), ("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("cell", C.c_float * 3),
-                ("inv_cell", C.c_float * 3), ("near_min", C.c_float * 3), ("near_max", C.c_float * 3)]
+                ("inv_cell", C.c_float * 3), ("near_min", C.c_float * 3), ("near_max", C.c_float * 3),
+                ("n_outliers", C.c_uint32), ("outlier_slot", C.c_uint32 * 4)]
 
 
 class RtDirListInfo(C.Structure):

@@ -58,6 +58,8 @@ static DirMaskParams dirmask_from_info(const rt_dirmask_info *info) {
     dm.near_min[a] = info->near_min[a];
     dm.near_max[a] = info->near_max[a];
   }
+  dm.n_outliers = info->n_outliers < kDirMaskMaxOutliers ? info->n_outliers : kDirMaskMaxOutliers;
+  for (uint32_t j = 0; j < dm.n_outliers; ++j) dm.outlier_slot[j] = info->outlier_slot[j];
   return dm;
 }
 
@@ -86,6 +88,8 @@ int rt_dirmask_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32
     info->near_min[a] = dm.near_min[a];
     info->near_max[a] = dm.near_max[a];
   }
+  info->n_outliers = dm.n_outliers;
+  for (uint32_t j = 0; j < dm.n_outliers; ++j) info->outlier_slot[j] = dm.outlier_slot[j];
   const size_t entries = static_cast<size_t>(dm.nx) * dm.ny * dm.nz * dm.bins;
   if (table && table_cap >= entries * dm.words)
     for (size_t e = 0; e < entries; ++e) {
@@ -109,6 +113,9 @@ int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, c
                   (o.y <= dm.near_max[1]) && (o.z >= dm.near_min[2]) && (o.z <= dm.near_max[2]);
   if (!ok) return RT_OK;
   *served = 1;
+  auto add_outliers = [&] {
+    for (uint32_t j = 0; j < dm.n_outliers; ++j) mask2[dm.outlier_slot[j] >> 6] |= 1ull << (dm.outlier_slot[j] & 63u);
+  };
   f3 p = o;
   const bool outside = !((o.x >= dm.bmin[0]) && (o.x <= dm.bmax[0]) && (o.y >= dm.bmin[1]) && (o.y <= dm.bmax[1]) && (o.z >= dm.bmin[2]) &&
                          (o.z <= dm.bmax[2]));
@@ -122,7 +129,10 @@ int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, c
     const float az = (dm.bmin[2] - o.z) * ivz, bz = (dm.bmax[2] - o.z) * ivz;
     const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    if (!(t_in <= t_out)) return RT_OK;  // misses the box: the empty set
+    if (!(t_in <= t_out)) {  // misses the box: the empty set — and the outliers, which every served ray tests
+      add_outliers();
+      return RT_OK;
+    }
     p = fma3(d, t_in, o);
   }
   const uint32_t cell = dirmask_cell(dm, p);
@@ -130,6 +140,7 @@ int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, c
   const size_t entry = static_cast<size_t>(cell) * dm.bins + dirmask_bin(d, inv_major, dm.k, dm.half_k);
   mask2[0] = table[entry * dm.words];
   if (dm.words > 1u) mask2[1] = table[entry * dm.words + 1u];
+  add_outliers();
   return RT_OK;
 }
 

@@ -1003,6 +1003,23 @@ __device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const Frame
       sh = scan_spheres_masked<4>(sv.sph, o, d, w.x, w.y, w.z, w.w);
   }
   if (planes_late && alive) hp = nearest_plane(sv, o, d);
+  if (dm.n_outliers != 0u) {  // wave-uniform, rare: spheres far from all the others are in no set (rt_dirmask.h "Outliers")
+    for (uint32_t j = 0; j < dm.n_outliers; ++j) {
+      const uint32_t i = dm.outlier_slot[j];
+      const float4 g = sv.sph[i];
+      const float nx = o.x - g.x, ny = o.y - g.y, nz = o.z - g.z;
+      const float dn = fmaf(d.z, nz, fmaf(d.y, ny, d.x * nx));
+      const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
+      if (fminf(q, -dn) >= 0.0f) {
+        const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;
+        // the lexicographic (key, slot) minimum: the linear scan's strict '<' in ascending slot order; kNoHitKey itself is no hit
+        if (key < sh.key || (key == sh.key && key < kNoHitKey && static_cast<int>(i) < sh.slot)) {
+          sh.key = key;
+          sh.slot = static_cast<int>(i);
+        }
+      }
+    }
+  }
   if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
     const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
     if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);

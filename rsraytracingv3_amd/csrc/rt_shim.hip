@@ -392,10 +392,11 @@ constexpr size_t kDirMaskMaxEntries = 8u << 20;  // 64 MB of one-word entries (1
 int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
   float4 reg[kDirMaskMaxSpheres];
   uint32_t target = static_cast<uint32_t>(ctx->dirmask_cells);
-  DirMaskParams dm = dirmask_plan(sph, n, target, static_cast<uint32_t>(ctx->dirmask_k), reg);
+  const bool take_outliers = !(ctx->flags & 32);  // RT_OPT_FLAGS bit 5: spheres far from the others stay in the table (A/B)
+  DirMaskParams dm = dirmask_plan(sph, n, target, static_cast<uint32_t>(ctx->dirmask_k), reg, take_outliers);
   while (dm.enabled && static_cast<size_t>(dm.nx) * dm.ny * dm.nz * dm.bins > kDirMaskMaxEntries && target > 1u) {
     target /= 2u;
-    dm = dirmask_plan(sph, n, target, static_cast<uint32_t>(ctx->dirmask_k), reg);
+    dm = dirmask_plan(sph, n, target, static_cast<uint32_t>(ctx->dirmask_k), reg, take_outliers);
   }
   if (!dm.enabled) return RT_OK;
   const size_t entries = static_cast<size_t>(dm.nx) * dm.ny * dm.nz * dm.bins;

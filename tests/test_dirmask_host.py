@@ -96,6 +96,35 @@ def test_sets_hold_for_other_views_and_scenes():
     check_scene(small, (64, 36), 2048, 8)
 
 
+def test_spheres_far_from_all_the_others_stay_out_of_the_table():
+    """rt_dirmask.h "Outliers": up to four spheres far from the rest are in no set — the cells and the registered radii are those of the
+    remaining spheres — and every served ray tests them directly (the host twin's lookup returns them with the set).  The headline
+    scene with three far spheres, two of them in view and one a mirror the paths bounce off: every sphere the oracle hit is in its
+    ray's set, the table's box is the cluster's, and the sets stay as small as without the outliers."""
+    from rsraytracingv3_amd.scene import Geometry, Material, Object
+    base = cases.headline_scene(6)
+    _, _, mean_base = check_scene(base, (64, 36), 4096, 8)
+    info_base, _ = build(sphere_records(base)[0], 4096, 8)
+    scene = cases.headline_scene(6)
+    mirror = Material((0.9, 0.9, 0.9), (0, 0, 0), 0.0, 0.5, 0.0)
+    far = [Geometry.sphere((-420.0, 60.0, -380.0), 90.0), Geometry.sphere((-900.0, 500.0, 100.0), 1.0), Geometry.sphere((30.0, 900.0, 30.0), 25.0)]
+    for k, g in enumerate(far):
+        scene.objects.insert(10 * k + 3, Object("far%d" % k, mirror, g))
+    sph, slots = sphere_records(scene)
+    info, table = build(sph, 4096, 8)
+    assert info.enabled and info.n_outliers == 3 and [info.outlier_slot[j] for j in range(3)] == [3, 13, 23]
+    for a in range(3):  # the cluster's box, not the bounding box of everything
+        assert abs(info.bmin[a] - info_base.bmin[a]) < 1.0 and abs(info.bmax[a] - info_base.bmax[a]) < 1.0
+    checked, served, mean = check_scene(scene, (64, 36), 4096, 8)
+    assert served > 0.85 * checked and mean < mean_base + 3.0 + 0.5
+    # the outliers are part of every served ray's set, also of one that misses the box
+    mask, ok = lookup(info, table, (0.0, float(info.bmax[1]) + 5.0, 0.0), (0.0, 1.0, 0.0))
+    assert ok and mask == (1 << 3) | (1 << 13) | (1 << 23)
+    # scenes without outliers: none taken
+    assert info_base.n_outliers == 0
+    assert build(sphere_records(cases.stress_scene(100, 4))[0], 4096, 8)[0].n_outliers == 0
+
+
 def test_the_reference_80_slot_scene_uses_two_word_sets():
     """connection.rs keeps 80 object slots, the unused ones zero-filled: radius-0 spheres at the origin the shader still
     tests.  64 spheres + 15 of those = 79 spheres -> two 64-bit words per entry."""

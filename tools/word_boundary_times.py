@@ -26,6 +26,8 @@ RenderTarget.new(dev, size)
 
 
 def measure(scene, max_objects, frames=640, batch=8):
+    dev.set_option(N.RT_OPT_FLAGS, 32 if max_objects == "live+32" else 0)
+    max_objects = "live" if max_objects == "live+32" else max_objects
     conn = Connection(scene, dev, sky, rt, max_objects=max_objects)
     conn.update_buffers(size, scene, (0.0, 0.0))
     best = 1e9
@@ -63,6 +65,9 @@ rows = [("64 spheres (live count)", base, "live"),
         ("63 spheres", minus_one([]), "live"),
         ("63 spheres + 1 of radius 0 at the origin (one-word sets)", minus_one([Geometry.sphere((0.0, 0.0, 0.0), 0.0)]), "live"),
         ("+ 1 sphere of radius 0 at the origin", plus([Geometry.sphere((0.0, 0.0, 0.0), 0.0)]), "live"),
+        ("+ 1 sphere of radius 1 at (-500, 500, -500), behind the camera (an outlier: tested by every ray)", plus([Geometry.sphere((-500.0, 500.0, -500.0), 1.0)]), "live"),
+        ("the same, the outlier kept in the table (RT_OPT_FLAGS 32)", plus([Geometry.sphere((-500.0, 500.0, -500.0), 1.0)]), "live+32"),
+        ("+ 3 far spheres", plus([Geometry.sphere((-500.0, 500.0, -500.0), 1.0), Geometry.sphere((-420.0, 60.0, -380.0), 90.0), Geometry.sphere((30.0, 900.0, 30.0), 25.0)]), "live"),
         ("the reference's 80 slots (zero-filled tail: 15 -> 1 record)", base, None)]
 for rep in range(2):
     for name, scene, mo in rows:
