@@ -395,6 +395,8 @@ RT_HD DirListGeom dirlist_geometry(const DirMaskParams &dm, uint32_t cell, uint3
 // Can a ray of the entry be accepted by the sphere {c, r_reg} at all — and if so, `dmin`: a lower bound of the distance
 // from the ray's lookup point to any point of the registered ball.  NaN anywhere -> yes, at distance 0.
 RT_HD bool dirlist_candidate(const DirListGeom &g, float4 reg, float &dmin) {
+  dmin = 0.0f;
+  if (reg.w < 0.0f) return false;  // an outlier (registered with radius -1, "Outliers" above): in no list, tested by every ray
   const float vx = reg.x - g.p.x, vy = reg.y - g.p.y, vz = reg.z - g.p.z;
   const float l2 = vx * vx + vy * vy + vz * vz;
   const float R = reg.w + g.h;
@@ -482,15 +484,25 @@ RT_HD void dirlist_entry(const DirMaskParams &dm, uint32_t cell, uint32_t bin, c
 
 // Host side: resolution, boxes and registered radii for n spheres {cx, cy, cz, r*r}; reg[i] receives {c, r_reg}.  Returns a
 // disabled plan for scenes the lists do not serve (no sphere, more than 65 535, non-finite data).
-inline DirMaskParams dirlist_plan(const float4 *sph, uint32_t n, uint32_t target_cells, uint32_t k, uint32_t reach_cells, float4 *reg) {
+inline DirMaskParams dirlist_plan(const float4 *sph, uint32_t n, uint32_t target_cells, uint32_t k, uint32_t reach_cells, float4 *reg,
+                                  bool take_outliers = true) {
   DirMaskParams dm{};
   if (n == 0 || n > kDirListMaxSpheres || k < 1 || k > kDirMaskMaxK || target_cells < 1 || reach_cells < 1) return dm;
   double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   std::vector<double> r(n);
+  for (uint32_t i = 0; i < n; ++i)
+    if (!(sph[i].w >= 0.0f) || !std::isfinite(sph[i].w) || !std::isfinite(sph[i].x) || !std::isfinite(sph[i].y) || !std::isfinite(sph[i].z)) return dm;
+  // spheres far from all the others stay out of the lists, as out of the bit sets ("Outliers" above): boxes, d_cap and the rounding
+  // terms are those of the rest, every ray tests them after its rounds (intersect_listed)
+  std::vector<char> outlier(n, 0);
+  if (take_outliers) {
+    dm.n_outliers = dirmask_outliers(sph, n, dm.outlier_slot);
+    for (uint32_t j = 0; j < dm.n_outliers; ++j) outlier[dm.outlier_slot[j]] = 1;
+  }
   for (uint32_t i = 0; i < n; ++i) {
     const double c[3] = {sph[i].x, sph[i].y, sph[i].z};
-    if (!(sph[i].w >= 0.0f) || !std::isfinite(sph[i].w) || !std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) return dm;
     r[i] = std::sqrt(static_cast<double>(sph[i].w));
+    if (outlier[i]) continue;
     for (int a = 0; a < 3; ++a) {
       lo[a] = std::fmin(lo[a], c[a] - r[i]);
       hi[a] = std::fmax(hi[a], c[a] + r[i]);
@@ -514,6 +526,7 @@ inline DirMaskParams dirlist_plan(const float4 *sph, uint32_t n, uint32_t target
       ghi[a] = -INFINITY;
     }
     for (uint32_t i = 0; i < n; ++i) {
+      if (outlier[i]) continue;
       const double eps = 0.003 * 1.01 * (d_cap + r[i]);
       rr[i] = 1.001 * std::sqrt(r[i] * r[i] + eps * eps) + 1e-3 * edge;
       const double c[3] = {sph[i].x, sph[i].y, sph[i].z};
@@ -558,7 +571,7 @@ inline DirMaskParams dirlist_plan(const float4 *sph, uint32_t n, uint32_t target
   const double reach = std::fmin(static_cast<double>(reach_cells) * edge, reach_bound);
   dm.reach_unit = static_cast<float>(reach / static_cast<double>(kDirListReachQuanta) * (1.0 - 1e-6));
   dm.s_cap = static_cast<float>(s_cap);
-  for (uint32_t i = 0; i < n; ++i) reg[i] = make_float4(sph[i].x, sph[i].y, sph[i].z, static_cast<float>(rr[i] * 1.0001));
+  for (uint32_t i = 0; i < n; ++i) reg[i] = make_float4(sph[i].x, sph[i].y, sph[i].z, outlier[i] ? -1.0f : static_cast<float>(rr[i] * 1.0001));
   dm.enabled = 1;
   dm.table = nullptr;
   return dm;

@@ -305,6 +305,11 @@ int rt_dirlist_walk_host(const rt_dirlist_info *info, const float *spheres_xyzr2
       }
     }
   }
+  for (uint32_t i = 0; i < n_spheres; ++i)  // the outliers (registered with radius -1): in no list, tested by every ray
+    if (registered_xyzr[4 * static_cast<size_t>(i) + 3] < 0.0f) {
+      test(i, *listed_key, *listed_slot);
+      *tests += 1;
+    }
   if (is_far) {
     *far = 1;
     *listed_key = *linear_key;

@@ -1229,6 +1229,22 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     else if (far) lin = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
     if (far) sh = lin;
   }
+  if (dm.n_outliers != 0u) {  // wave-uniform, rare: spheres far from all the others are in no list (rt_dirmask.h "Outliers")
+    for (uint32_t j = 0; j < dm.n_outliers; ++j) {
+      const uint32_t i = dm.outlier_slot[j];
+      const float4 g = sv.sph[i];
+      const float nx = o.x - g.x, ny = o.y - g.y, nz = o.z - g.z;
+      const float dn = fmaf(d.z, nz, fmaf(d.y, ny, d.x * nx));
+      const float qd = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
+      if (fminf(qd, -dn) >= 0.0f) {
+        const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(qd)) - kEpsBits;
+        if (key < sh.key || (key == sh.key && key < kNoHitKey && static_cast<int>(i) < sh.slot)) {
+          sh.key = key;
+          sh.slot = static_cast<int>(i);
+        }
+      }
+    }
+  }
   const Hit merged = alive ? ((LEAN && RT_LAZY_OBJ) ? merge_sphere_hit_lazy(sv, hp, sh) : merge_sphere_hit(sv, hp, sh)) : miss;
   if (!LEAN && fp.cull_check && alive) {
     // self-check frame: the linear scan must lead to the same hit.  (The sphere results themselves may differ: a plane hit inside
@@ -2490,7 +2506,7 @@ __global__ void __launch_bounds__(256) dirlist_build_kernel(DirMaskParams dm, co
       const float vx = r.x - g0.p.x, vy = r.y - g0.p.y, vz = r.z - g0.p.z;
       const float l2 = vx * vx + vy * vy + vz * vz;
       const float R = r.w + g0.h;
-      near = !(l2 > R * R * 1.0001f) || !(fmaxf(sqrtf(l2) * 0.9999f - R, 0.0f) > reach_max);
+      near = r.w >= 0.0f && (!(l2 > R * R * 1.0001f) || !(fmaxf(sqrtf(l2) * 0.9999f - R, 0.0f) > reach_max));  // (r.w < 0: an outlier)
     }
     const unsigned long long m = __builtin_amdgcn_ballot_w64(near);
     if (lane == 0) wave_count[wave] = static_cast<uint32_t>(__popcll(m));

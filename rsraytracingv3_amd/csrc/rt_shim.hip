@@ -449,10 +449,10 @@ int build_dirlist(rt_context *ctx, const float4 *sph, uint32_t n) {
   uint32_t reach = static_cast<uint32_t>(ctx->dirlist_reach);
   const uint32_t k = static_cast<uint32_t>(ctx->dirlist_k);
   auto bytes_of = [](const DirMaskParams &d) { return (static_cast<size_t>(d.nx) * d.ny * d.nz * d.bins + 1u) * 32u; };
-  DirMaskParams dm = dirlist_plan(sph, n, target, k, reach, reg.data());
+  DirMaskParams dm = dirlist_plan(sph, n, target, k, reach, reg.data(), !(ctx->flags & 32));
   while (dm.enabled && bytes_of(dm) > kDirListMaxBytes && target > 1u) {
     target /= 2u;
-    dm = dirlist_plan(sph, n, target, k, reach, reg.data());
+    dm = dirlist_plan(sph, n, target, k, reach, reg.data(), !(ctx->flags & 32));
   }
   if (!dm.enabled || bytes_of(dm) > kDirListMaxBytes) return RT_OK;
   for (;;) {
@@ -463,7 +463,7 @@ int build_dirlist(rt_context *ctx, const float4 *sph, uint32_t n) {
     const bool same = ctx->d_dirmask && key.size() == ctx->dirmask_built_for.size() &&
                       std::memcmp(key.data(), ctx->dirmask_built_for.data(), key.size() * sizeof(float4)) == 0;
     if (same) {  // (the reach it ended up with is part of the kept state)
-      dm = dirlist_plan(sph, n, target, k, ctx->dirlist_reach_used, reg.data());
+      dm = dirlist_plan(sph, n, target, k, ctx->dirlist_reach_used, reg.data(), !(ctx->flags & 32));
       break;
     }
     ctx->dirmask_built_for.clear();
@@ -498,7 +498,7 @@ int build_dirlist(rt_context *ctx, const float4 *sph, uint32_t n) {
       RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
       if (overflow == 0u || reach_now <= 1u) break;
       reach_now = reach_now / 2u;
-      dm = dirlist_plan(sph, n, target, k, reach_now, reg.data());
+      dm = dirlist_plan(sph, n, target, k, reach_now, reg.data(), !(ctx->flags & 32));
     }
     ctx->dirlist_reach_used = reach_now;
     ctx->dirmask_built_for = key;

@@ -112,6 +112,32 @@ def test_walk_equals_linear_scan_on_other_views_and_scenes():
     check_oracle_rays(medium, (64, 36), Lists(msph, cells=2048, k=4, reach=3))
 
 
+def test_spheres_far_from_all_the_others_stay_out_of_the_lists():
+    """rt_dirmask.h "Outliers", for the lists: three far spheres (a big mirror the paths bounce off, a tiny one, one overhead) added to
+    a 300-sphere scene are registered with radius -1, the table's box and cells stay the cluster's, and the walk — which tests them after
+    its rounds — still equals the linear scan on every ray of the oracle, with lists as short as without them."""
+    from rsraytracingv3_amd.scene import Geometry, Material, Object
+    base = cases.stress_scene(300, 6)
+    plain = Lists(sphere_records(base)[0], cells=4096, k=6, reach=8)
+    _, _, tests_plain, _ = check_oracle_rays(base, (64, 36), plain, every=2)
+    scene = cases.stress_scene(300, 6)
+    mirror = Material((0.9, 0.9, 0.9), (0, 0, 0), 0.0, 0.5, 0.0)
+    far = [Geometry.sphere((-1200.0, 200.0, -1100.0), 250.0), Geometry.sphere((-1500.0, 1500.0, -1500.0), 1.0), Geometry.sphere((100.0, 2500.0, 100.0), 60.0)]
+    for k, g in enumerate(far):
+        scene.objects.insert(40 * k + 7, Object("far%d" % k, mirror, g))
+    sph, _ = sphere_records(scene)
+    lists = Lists(sph, cells=4096, k=6, reach=8)
+    assert lists.info.enabled
+    assert [i for i in range(len(sph)) if lists.reg[i, 3] < 0] == [7, 47, 87]
+    for a in range(3):
+        assert abs(lists.info.bmin[a] - plain.info.bmin[a]) < 2.0 and abs(lists.info.bmax[a] - plain.info.bmax[a]) < 2.0
+    checked, far_n, tests, rounds = check_oracle_rays(scene, (64, 36), lists, every=2)
+    assert checked > 1000 and tests < tests_plain + 3.0 + 1.0
+    for cell in (0, 1000, 3000):  # and no entry lists them
+        for b in (0, 17, 100):
+            assert not set(lists.entry(cell, b)[2]) & {7, 47, 87}
+
+
 def test_random_rays_inside_outside_and_degenerate():
     rng = np.random.default_rng(5)
     scene = cases.stress_scene(300, 8)

@@ -765,23 +765,25 @@ def test_degenerate_spheres_around_ray_origins(device, variant):
 
 
 @pytest.mark.parametrize("variant", [0, 3])
-def test_spheres_far_from_the_others_are_tested_outside_the_table(device, variant):
+@pytest.mark.parametrize("kind", ["bit_sets", "lists"])
+def test_spheres_far_from_the_others_are_tested_outside_the_table(device, variant, kind):
     """rt_dirmask.h "Outliers": the headline scene with three far spheres — a big mirror in view that paths bounce off and back into
     the scene, a tiny one, one overhead —: they are in no set of the table and every served ray tests them directly.  Frames, segment
     counts and hit indices are the oracle's, from two cameras (one of them next to the far mirror: rays that start outside the near box
     scan linearly), RT_OPT_CULL = 2 counts no disagreement with the linear scan, and with RT_OPT_FLAGS bit 5 (the outliers stay in the
     table) the frames are the same."""
     from rsraytracingv3_amd.scene import Camera, Geometry, Material, Object
-    scene = cases.headline_scene(6)
+    scene = cases.headline_scene(6) if kind == "bit_sets" else cases.stress_scene(300, 6)  # (the same for the candidate lists)
     mirror = Material((0.9, 0.9, 0.9), (0, 0, 0), 0.0, 0.5, 0.0)
     rough = Material((0.9, 0.4, 0.3), (1.0, 1.0, 1.0), 0.5, 0.5, 0.7)
-    far = [(Geometry.sphere((-420.0, 60.0, -380.0), 90.0), mirror), (Geometry.sphere((-900.0, 500.0, 100.0), 1.0), rough),
-           (Geometry.sphere((30.0, 900.0, 30.0), 25.0), rough)]
+    f = 1.0 if kind == "bit_sets" else 3.0
+    far = [(Geometry.sphere((-420.0 * f, 60.0 * f, -380.0 * f), 90.0 * f), mirror), (Geometry.sphere((-900.0 * f, 500.0 * f, 100.0 * f), 1.0), rough),
+           (Geometry.sphere((30.0 * f, 900.0 * f, 30.0 * f), 25.0 * f), rough)]
     for k, (g, m) in enumerate(far):
         scene.objects.insert(10 * k + 3, Object("far%d" % k, m, g))
     sky, rnd = cases.inputs(128, 64)
     size, jitter = (192, 108), (-0.1, 0.35)
-    for cam in (scene.camera, Camera((-300.0, 80.0, -270.0), (0.2, 2.4, 0.0), 70.0)):
+    for cam in (scene.camera, Camera((-300.0 * f, 80.0 * f, -270.0 * f), (0.2, 2.4, 0.0), 70.0)):
         scene.camera = cam
         ref = run_oracle(scene, size, sky, rnd, jitter, max_objects="live")
         for flags in (0, 32):
@@ -793,7 +795,7 @@ def test_spheres_far_from_the_others_are_tested_outside_the_table(device, varian
                 device.set_option(N.RT_OPT_FLAGS, 0)
                 device.set_option(N.RT_OPT_CULL, 1)
             assert_frame_equal(outs[0], ref)
-            assert st.last_cull_mismatches == 0 and st.dirmask_cells > 0
+            assert st.last_cull_mismatches == 0 and st.dirmask_cells > 0 and (st.dirmask_lists > 0) == (kind == "lists")
             assert st.last_segments == int(ref.segments.sum())
 
 
