@@ -29,6 +29,12 @@ def random_case(seed):
         emis = float(rs.choice([0.0, 0.0, rs.uniform(0, 12)]))
         objs.append(Object("s%d" % i, Material(tuple(map(float, rs.uniform(0, 1, 3))), tuple(map(float, rs.randint(0, 2, 3))),
                                               emis, 0.5, rough), Geometry.sphere(c, r)))
+    if n_sph >= 12 and rs.randint(0, 4) == 0:  # spheres far from all the others: taken out of the candidate tables (rt_dirmask.h "Outliers")
+        for j in range(int(rs.randint(1, 7))):  # up to four are taken, the others stay in
+            c = tuple(float(v) for v in rs.uniform(-1.0, 1.0, 3) * extent * rs.choice([6.0, 15.0, 40.0]))
+            objs.insert(int(rs.randint(0, len(objs) + 1)),
+                        Object("far%d" % j, Material(tuple(map(float, rs.uniform(0, 1, 3))), (1.0, 1.0, 1.0), float(rs.choice([0.0, 2.0])), 0.5,
+                                                     float(rs.choice([0.0, 0.4]))), Geometry.sphere(c, float(extent * rs.choice([0.01, 0.5, 3.0])))))
     for j in range(int(rs.choice([0, 1, 1, 3]))):
         nrm = rs.normal(size=3)
         nrm = tuple(float(v) for v in (nrm / np.linalg.norm(nrm) * rs.choice([1.0, 1.0, 2.5])))
