@@ -346,8 +346,8 @@ enum {
                               units a wave takes off the path queue at a time */
   RT_OPT_FLAGS = 4,        /* experiment switches: bit 1 (2) ignore the sphere grid; bit 2 (4) launches of every size spill their
                               tail (RT_OPT_TAIL_SPILL) — speed only, frames stay bit-identical; bit 3 (8) rt_set_scene keeps sphere records that repeat an
-                              earlier one (rt_stats.spheres_scanned) — speed only; bit 5 (32) spheres far from all the others stay in the direction-mask
-                              table instead of being tested by every ray (rt_dirmask_info.n_outliers) — speed only; bit 4 (16) DRY launches: every
+                              earlier one (rt_stats.spheres_scanned) — speed only; bit 5 (32) spheres far from all the others size the candidate
+                              tables like any other instead of being entered into every set (rt_dirmask_info.n_outliers) — speed only; bit 4 (16) DRY launches: every
                               kernel of a launch (render, tail, resolve, assembly) runs ONE workgroup and peer copies move one row —
                               all of a frame's host calls, events and stream waits with next to none of its device work, to tell
                               host time from device time (tools/multi_times.py); the frames are garbage                         */
@@ -427,8 +427,8 @@ RT355_API int rt_grid_build_host(const float *spheres_xyzr2, uint32_t n_spheres,
 typedef struct rt_dirmask_info {
   uint32_t enabled, nx, ny, nz, k, bins, words;
   float bmin[3], bmax[3], cell[3], inv_cell[3], near_min[3], near_max[3];
-  uint32_t n_outliers, outlier_slot[4]; /* spheres far from all the others: in no set of the table, tested by every served ray
-                                           (rt_dirmask_lookup_host adds them to the set it returns)                          */
+  uint32_t n_outliers, outlier_slot[4]; /* spheres far from all the others: they do not size the table (boxes, cells, rounding term)
+                                           and are members of every set instead                                              */
 } rt_dirmask_info;
 RT355_API int rt_dirmask_build_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t target_cells, uint32_t k,
                                     rt_dirmask_info *info, uint64_t *table, size_t table_cap);
@@ -446,6 +446,8 @@ RT355_API int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t
 typedef struct rt_dirlist_info {
   uint32_t enabled, nx, ny, nz, k, bins;
   float bmin[3], bmax[3], cell[3], inv_cell[3], reach_unit, s_cap;
+  uint32_t n_outliers, outlier_slot[4]; /* spheres far from all the others: registered with radius -1, they do not size the table
+                                           and are listed by every entry instead                                                */
 } rt_dirlist_info;
 RT355_API int rt_dirlist_plan_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_t target_cells, uint32_t k,
                                    uint32_t reach_cells, rt_dirlist_info *info, float *registered_xyzr);

@@ -63,7 +63,8 @@ class RtDirMaskInfo(C.Structure):
 class RtDirListInfo(C.Structure):
     _fields_ = [("enabled", C.c_uint32), ("nx", C.c_uint32), ("ny", C.c_uint32), ("nz", C.c_uint32), ("k", C.c_uint32),
                 ("bins", C.c_uint32), ("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("cell", C.c_float * 3),
-                ("inv_cell", C.c_float * 3), ("reach_unit", C.c_float), ("s_cap", C.c_float)]
+                ("inv_cell", C.c_float * 3), ("reach_unit", C.c_float), ("s_cap", C.c_float),
+                ("n_outliers", C.c_uint32), ("outlier_slot", C.c_uint32 * 4)]
 
 
 class RtDeviceBuffers(C.Structure):

@@ -58,9 +58,10 @@ struct DirMaskParams {
   uint32_t lists;      // 1: list entries
   float reach_unit;    // world units per quantum of an entry's reach
   float s_cap;         // lookups are served for ray parameters up to this; beyond it a ray scans linearly
-  // bit sets only: spheres far from all the others ("Outliers" below) are in no set; every served ray tests them directly
+  // spheres far from all the others ("Outliers" below) do not size the table; they are members of every set / list instead
   uint32_t n_outliers;
   uint32_t outlier_slot[4];
+  unsigned long long outlier_mask[2];  // their bits (bit sets: the extra entry rays that miss the box read)
 };
 constexpr uint32_t kDirMaskMaxOutliers = 4;
 
@@ -141,11 +142,10 @@ RT_HD void dirmask_entry(const DirMaskParams &dm, uint32_t cell, uint32_t bin, c
   unsigned long long m0 = 0ull, m1 = 0ull;
   for (uint32_t i = 0; i < n; ++i) {
     const float4 g = reg[i];
-    if (g.w < 0.0f) continue;  // an outlier (registered with radius -1): in no set, tested by every ray
     const float vx = g.x - p.x, vy = g.y - p.y, vz = g.z - p.z;
     const float l2 = vx * vx + vy * vy + vz * vz;
     const float R = g.w + h;
-    bool in = !(l2 > R * R * 1.0001f);  // the cell (grown) touches the registered ball; NaN -> in
+    bool in = g.w < 0.0f || !(l2 > R * R * 1.0001f);  // an outlier (registered with radius -1: in EVERY set), or the cell (grown) touches the registered ball; NaN -> in
     if (!in) {
       const float inv_l = 1.0f / sqrtf(l2);
       const float s = fminf(R * inv_l * 1.0001f, 1.0f);  // sin(phi), phi = asin(R / |c - p|)
@@ -165,9 +165,9 @@ RT_HD void dirmask_entry(const DirMaskParams &dm, uint32_t cell, uint32_t bin, c
 // Outliers.  Everything above is sized by the spheres' bounding box: the cells divide the box of all registered balls, and the
 // rounding term of every registered radius is 0.003 x the near box's diagonal.  ONE sphere far from the others (a distant light, an
 // object dragged away in the editor) makes the cells ten times coarser and every ball fatter — the headline scene plus a sphere 860
-// units away ran at 37 Grays/s instead of 57.  So up to four spheres far from all the others are taken OUT of the table: they are in
-// no set, the boxes and the rounding term are those of the remaining spheres, and every served ray tests them directly, after its set,
-// with the arithmetic of the linear scan and the lexicographic (key, slot) rule (intersect_masked) — a set plus the outliers still
+// units away ran at 37 Grays/s instead of 57.  So up to four spheres far from all the others are taken out of the table's GEOMETRY: the
+// boxes and the rounding term are those of the remaining spheres, and the outliers are members of EVERY set instead (no cone test:
+// the builder lists them unconditionally) — also of the extra set behind the table that rays missing the box read —, so a set still
 // holds every sphere the float test can accept.  (A ray that starts on a distant outlier is outside the near box and not served, as before.)
 // Which: with c_med the per-axis median of the centres and e_i = |c_i - c_med| + r_i, the spheres with e_i > 3 x the 75th percentile
 // of e, farthest first, while at least eight spheres remain.
@@ -219,7 +219,10 @@ inline DirMaskParams dirmask_plan(const float4 *sph, uint32_t n, uint32_t target
   bool outlier[kDirMaskMaxSpheres] = {};
   if (take_outliers) {
     dm.n_outliers = dirmask_outliers(sph, n, dm.outlier_slot);
-    for (uint32_t j = 0; j < dm.n_outliers; ++j) outlier[dm.outlier_slot[j]] = true;
+    for (uint32_t j = 0; j < dm.n_outliers; ++j) {
+      outlier[dm.outlier_slot[j]] = true;
+      dm.outlier_mask[dm.outlier_slot[j] >> 6] |= 1ull << (dm.outlier_slot[j] & 63u);
+    }
   }
   for (uint32_t i = 0; i < n; ++i) {
     const double c[3] = {sph[i].x, sph[i].y, sph[i].z};
@@ -396,7 +399,7 @@ RT_HD DirListGeom dirlist_geometry(const DirMaskParams &dm, uint32_t cell, uint3
 // from the ray's lookup point to any point of the registered ball.  NaN anywhere -> yes, at distance 0.
 RT_HD bool dirlist_candidate(const DirListGeom &g, float4 reg, float &dmin) {
   dmin = 0.0f;
-  if (reg.w < 0.0f) return false;  // an outlier (registered with radius -1, "Outliers" above): in no list, tested by every ray
+  if (reg.w < 0.0f) return true;  // an outlier (registered with radius -1, "Outliers" above): in every list, at distance 0
   const float vx = reg.x - g.p.x, vy = reg.y - g.p.y, vz = reg.z - g.p.z;
   const float l2 = vx * vx + vy * vy + vz * vz;
   const float R = reg.w + g.h;

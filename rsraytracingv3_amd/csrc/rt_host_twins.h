@@ -129,7 +129,7 @@ int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, c
     const float az = (dm.bmin[2] - o.z) * ivz, bz = (dm.bmax[2] - o.z) * ivz;
     const float t_in = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     const float t_out = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    if (!(t_in <= t_out)) {  // misses the box: the empty set — and the outliers, which every served ray tests
+    if (!(t_in <= t_out)) {  // misses the box: the device reads the extra entry that holds the outliers alone
       add_outliers();
       return RT_OK;
     }
@@ -138,9 +138,8 @@ int rt_dirmask_lookup_host(const rt_dirmask_info *info, const uint64_t *table, c
   const uint32_t cell = dirmask_cell(dm, p);
   const float inv_major = 1.0f / fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
   const size_t entry = static_cast<size_t>(cell) * dm.bins + dirmask_bin(d, inv_major, dm.k, dm.half_k);
-  mask2[0] = table[entry * dm.words];
+  mask2[0] = table[entry * dm.words];  // (every entry holds the outliers)
   if (dm.words > 1u) mask2[1] = table[entry * dm.words + 1u];
-  add_outliers();
   return RT_OK;
 }
 
@@ -166,6 +165,8 @@ static DirMaskParams dirlist_from_info(const rt_dirlist_info *info) {
     dm.cell[a] = info->cell[a];
     dm.inv_cell[a] = info->inv_cell[a];
   }
+  dm.n_outliers = info->n_outliers < kDirMaskMaxOutliers ? info->n_outliers : kDirMaskMaxOutliers;
+  for (uint32_t j = 0; j < dm.n_outliers; ++j) dm.outlier_slot[j] = info->outlier_slot[j];
   return dm;
 }
 
@@ -193,6 +194,8 @@ int rt_dirlist_plan_host(const float *spheres_xyzr2, uint32_t n_spheres, uint32_
       info->cell[a] = dm.cell[a];
       info->inv_cell[a] = dm.inv_cell[a];
     }
+    info->n_outliers = dm.n_outliers;
+    for (uint32_t j = 0; j < dm.n_outliers; ++j) info->outlier_slot[j] = dm.outlier_slot[j];
     if (registered_xyzr) std::memcpy(registered_xyzr, reg.data(), static_cast<size_t>(n_spheres) * sizeof(float4));
     return RT_OK;
   } catch (...) {
@@ -264,9 +267,11 @@ int rt_dirlist_walk_host(const rt_dirlist_info *info, const float *spheres_xyzr2
     const bool finite = (o.x == o.x) && (o.y == o.y) && (o.z == o.z);
     const bool misses = finite && !(t_in <= t_out);
     const bool beyond = !finite || (t_in > dm.s_cap);
-    s = t_in;
+    // (with outliers — listed by every entry — a ray that misses the box still looks the entry up where it starts: intersect_listed)
+    const bool keep_missing = dm.n_outliers != 0u;
+    s = (misses && keep_missing) ? 0.0f : t_in;
     is_far = beyond;
-    todo = !misses && !beyond;
+    todo = !(misses && !keep_missing) && !beyond;
   }
   const float inv_major = 1.0f / fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
   const uint32_t bin = unit ? dirmask_bin(d, inv_major, dm.k, dm.half_k) : 0u;
@@ -305,11 +310,6 @@ int rt_dirlist_walk_host(const rt_dirlist_info *info, const float *spheres_xyzr2
       }
     }
   }
-  for (uint32_t i = 0; i < n_spheres; ++i)  // the outliers (registered with radius -1): in no list, tested by every ray
-    if (registered_xyzr[4 * static_cast<size_t>(i) + 3] < 0.0f) {
-      test(i, *listed_key, *listed_slot);
-      *tests += 1;
-    }
   if (is_far) {
     *far = 1;
     *listed_key = *linear_key;

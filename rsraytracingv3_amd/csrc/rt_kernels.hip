@@ -638,7 +638,9 @@ __device__ __forceinline__ bool dirmask_lookup(const DirMaskParams &dm, f3 o, f3
   const uint32_t cell = dirmask_cell(dm, p);
   const float inv_major = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
   const uint32_t bin = dirmask_bin(d, inv_major, dm.k, dm.half_k);
-  entry = (alive & reaches) ? cell * dm.bins + bin : dm.entries;
+  // two more entries behind the table: the all-zero one for lanes without a ray, and for rays that miss the box the set of the spheres
+  // far from all the others ("Outliers", rt_dirmask.h: every entry of the table holds them too) — empty for most scenes
+  entry = alive ? (reaches ? cell * dm.bins + bin : dm.entries + 1u) : dm.entries;
   return true;
 }
 
@@ -1003,23 +1005,6 @@ __device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const Frame
       sh = scan_spheres_masked<4>(sv.sph, o, d, w.x, w.y, w.z, w.w);
   }
   if (planes_late && alive) hp = nearest_plane(sv, o, d);
-  if (dm.n_outliers != 0u) {  // wave-uniform, rare: spheres far from all the others are in no set (rt_dirmask.h "Outliers")
-    for (uint32_t j = 0; j < dm.n_outliers; ++j) {
-      const uint32_t i = dm.outlier_slot[j];
-      const float4 g = sv.sph[i];
-      const float nx = o.x - g.x, ny = o.y - g.y, nz = o.z - g.z;
-      const float dn = fmaf(d.z, nz, fmaf(d.y, ny, d.x * nx));
-      const float q = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
-      if (fminf(q, -dn) >= 0.0f) {
-        const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(q)) - kEpsBits;
-        // the lexicographic (key, slot) minimum: the linear scan's strict '<' in ascending slot order; kNoHitKey itself is no hit
-        if (key < sh.key || (key == sh.key && key < kNoHitKey && static_cast<int>(i) < sh.slot)) {
-          sh.key = key;
-          sh.slot = static_cast<int>(i);
-        }
-      }
-    }
-  }
   if (!LEAN && fp.cull_check && alive) {  // self-check frame: the linear scan must agree
     const SphereHit full = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
     if (full.key != sh.key || full.slot != sh.slot) atomicAdd(&fp.counters[3], 1ull);
@@ -1037,6 +1022,9 @@ __device__ __forceinline__ Hit intersect_masked(const SceneView &sv, const Frame
 // not serve (direction not a unit vector, NaN, farther along than s_cap, an entry without a reach) scan linearly at the end,
 // together (the cooperative scan when they are few).  The planes are tested under the first round's load.
 // `scratch_base`: kListScratchBytes per wave.
+#ifndef RT_LIST_OUTLIERS
+#define RT_LIST_OUTLIERS 1
+#endif
 template <bool LEAN, bool TRIPS2 = (RT_LIST_TRIPS2 != 0)>
 __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const FrameParams &fp, f3 o, f3 d, bool alive, Hit miss,
                                                 unsigned char *scratch_base RT_PH_PARAMS) {
@@ -1078,9 +1066,13 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     const bool finite = (o.x == o.x) & (o.y == o.y) & (o.z == o.z);
     const bool misses = outside & finite & !(t_in <= t_out);
     const bool beyond = outside & (!finite | (t_in > dm.s_cap));  // (a NaN t_in with a finite origin cannot happen: d is a unit vector)
-    s = outside ? t_in : 0.0f;
+    // Spheres far from all the others ("Outliers", rt_dirmask.h) are listed by EVERY entry: with such a scene a ray that misses the box
+    // still looks one entry up, where it starts (the cell index clamps into the grid; that cell's other spheres are tested for nothing),
+    // and leaves the rounds at its first step.
+    const bool keep_missing = RT_LIST_OUTLIERS && dm.n_outliers != 0u;
+    s = (outside & !(misses & keep_missing)) ? t_in : 0.0f;
     far |= beyond;
-    todo &= !misses & !beyond;
+    todo &= !(misses & !keep_missing) & !beyond;
   }
   const float inv_major = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)));
   const uint32_t bin = dirmask_bin(d, inv_major, dm.k, dm.half_k);
@@ -1228,22 +1220,6 @@ __device__ __forceinline__ Hit intersect_listed(const SceneView &sv, const Frame
     if (n_far <= 32u) lin = scan_spheres_coop(sv.sph, sv.n_sph_pad, o, d, far, far_mask, n_far);
     else if (far) lin = scan_spheres(sv.sph, 0u, sv.n_sph_pad - kSphBatch, o, d);
     if (far) sh = lin;
-  }
-  if (dm.n_outliers != 0u) {  // wave-uniform, rare: spheres far from all the others are in no list (rt_dirmask.h "Outliers")
-    for (uint32_t j = 0; j < dm.n_outliers; ++j) {
-      const uint32_t i = dm.outlier_slot[j];
-      const float4 g = sv.sph[i];
-      const float nx = o.x - g.x, ny = o.y - g.y, nz = o.z - g.z;
-      const float dn = fmaf(d.z, nz, fmaf(d.y, ny, d.x * nx));
-      const float qd = fmaf(dn, dn, -(fmaf(nz, nz, fmaf(ny, ny, nx * nx)) - g.w));
-      if (fminf(qd, -dn) >= 0.0f) {
-        const uint32_t key = __float_as_uint(-dn - sqrt_for_hit(qd)) - kEpsBits;
-        if (key < sh.key || (key == sh.key && key < kNoHitKey && static_cast<int>(i) < sh.slot)) {
-          sh.key = key;
-          sh.slot = static_cast<int>(i);
-        }
-      }
-    }
   }
   const Hit merged = alive ? ((LEAN && RT_LAZY_OBJ) ? merge_sphere_hit_lazy(sv, hp, sh) : merge_sphere_hit(sv, hp, sh)) : miss;
   if (!LEAN && fp.cull_check && alive) {
@@ -2464,10 +2440,10 @@ __global__ void __launch_bounds__(256) dirmask_build_kernel(DirMaskParams dm, co
   if (threadIdx.x < n) s_reg[threadIdx.x] = reg[threadIdx.x];  // n <= 128 < 256 threads
   __syncthreads();
   const unsigned long long e = static_cast<unsigned long long>(blockIdx.x) * 256ull + threadIdx.x;
-  if (e > entries) return;
-  if (e == entries) {  // the extra all-zero entry lanes without a ray read
-    table[e * dm.words] = 0ull;
-    if (dm.words > 1u) table[e * dm.words + 1u] = 0ull;
+  if (e > entries + 1ull) return;
+  if (e >= entries) {  // the two extra entries: all-zero (lanes without a ray), the outliers alone (rays that miss the box)
+    table[e * dm.words] = e == entries ? 0ull : dm.outlier_mask[0];
+    if (dm.words > 1u) table[e * dm.words + 1u] = e == entries ? 0ull : dm.outlier_mask[1];
     return;
   }
   unsigned long long w[2];
@@ -2506,7 +2482,7 @@ __global__ void __launch_bounds__(256) dirlist_build_kernel(DirMaskParams dm, co
       const float vx = r.x - g0.p.x, vy = r.y - g0.p.y, vz = r.z - g0.p.z;
       const float l2 = vx * vx + vy * vy + vz * vz;
       const float R = r.w + g0.h;
-      near = r.w >= 0.0f && (!(l2 > R * R * 1.0001f) || !(fmaxf(sqrtf(l2) * 0.9999f - R, 0.0f) > reach_max));  // (r.w < 0: an outlier)
+      near = r.w < 0.0f || !(l2 > R * R * 1.0001f) || !(fmaxf(sqrtf(l2) * 0.9999f - R, 0.0f) > reach_max);  // (r.w < 0: an outlier, in every entry)
     }
     const unsigned long long m = __builtin_amdgcn_ballot_w64(near);
     if (lane == 0) wave_count[wave] = static_cast<uint32_t>(__popcll(m));
@@ -2877,8 +2853,8 @@ int launch_cull_tiles(const DeviceScene &sc, const FrameParams &fp, unsigned lon
 int launch_dirmask_build(const DirMaskParams &dm, const float4 *reg, uint32_t n, unsigned long long *table, hipStream_t stream) {
   const unsigned long long entries = static_cast<unsigned long long>(dm.nx) * dm.ny * dm.nz * dm.bins;
   if (entries == 0 || n == 0 || n > kDirMaskMaxSpheres) return static_cast<int>(hipErrorInvalidValue);
-  hipLaunchKernelGGL(dirmask_build_kernel, dim3(static_cast<uint32_t>((entries + 256ull) / 256ull)), dim3(256), 0, stream, dm, reg, n,
-                     table, entries);  // entries + 1 threads: the last writes the zero entry
+  hipLaunchKernelGGL(dirmask_build_kernel, dim3(static_cast<uint32_t>((entries + 257ull) / 256ull)), dim3(256), 0, stream, dm, reg, n,
+                     table, entries);  // entries + 2 threads: the last two write the extra entries
   return static_cast<int>(hipGetLastError());
 }
 

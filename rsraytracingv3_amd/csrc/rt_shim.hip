@@ -408,7 +408,7 @@ int build_dirmask(rt_context *ctx, const float4 *sph, uint32_t n) {
                     std::memcmp(key.data(), ctx->dirmask_built_for.data(), key.size() * sizeof(float4)) == 0;
   if (!same) {
     ctx->dirmask_built_for.clear();
-    const size_t need_words = (entries + 1u) * dm.words;  // + the all-zero entry
+    const size_t need_words = (entries + 2u) * dm.words;  // + the all-zero entry and the outliers' entry
     if (ctx->dirmask_cap < need_words) {
       (void)hipFree(ctx->d_dirmask);
       ctx->d_dirmask = nullptr;

@@ -114,8 +114,8 @@ def test_walk_equals_linear_scan_on_other_views_and_scenes():
 
 def test_spheres_far_from_all_the_others_stay_out_of_the_lists():
     """rt_dirmask.h "Outliers", for the lists: three far spheres (a big mirror the paths bounce off, a tiny one, one overhead) added to
-    a 300-sphere scene are registered with radius -1, the table's box and cells stay the cluster's, and the walk — which tests them after
-    its rounds — still equals the linear scan on every ray of the oracle, with lists as short as without them."""
+    a 300-sphere scene are registered with radius -1: the table's box and cells stay the cluster's, every entry lists them (no cone
+    test), and the walk still equals the linear scan on every ray of the oracle, with lists as short as without them plus three."""
     from rsraytracingv3_amd.scene import Geometry, Material, Object
     base = cases.stress_scene(300, 6)
     plain = Lists(sphere_records(base)[0], cells=4096, k=6, reach=8)
@@ -132,10 +132,16 @@ def test_spheres_far_from_all_the_others_stay_out_of_the_lists():
     for a in range(3):
         assert abs(lists.info.bmin[a] - plain.info.bmin[a]) < 2.0 and abs(lists.info.bmax[a] - plain.info.bmax[a]) < 2.0
     checked, far_n, tests, rounds = check_oracle_rays(scene, (64, 36), lists, every=2)
-    assert checked > 1000 and tests < tests_plain + 3.0 + 1.0
-    for cell in (0, 1000, 3000):  # and no entry lists them
+    assert checked > 1000 and tests < tests_plain + 3.0 * rounds + 1.0  # three more tests per round
+    for cell in (0, 1000, 3000):  # every entry that serves rays lists them (no cone test for an outlier), in slot order
         for b in (0, 17, 100):
-            assert not set(lists.entry(cell, b)[2]) & {7, 47, 87}
+            n, q, slots = lists.entry(cell, b)
+            assert q == 0 or ({7, 47, 87} <= set(slots) and slots == sorted(slots))
+    # a ray that misses the cluster's box still finds them: one lookup where it starts
+    o = np.array([0.0, float(lists.info.bmax[1]) + 50.0, 0.0], np.float32)
+    d = np.array([100.0, 2500.0, 100.0], np.float32) - o
+    listed, linear, r, t, far = lists.walk(o, (d / np.linalg.norm(d)).astype(np.float32))
+    assert listed == linear and not far and r == 1 and linear[1] == 87  # the sphere overhead
 
 
 def test_random_rays_inside_outside_and_degenerate():

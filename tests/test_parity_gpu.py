@@ -766,9 +766,9 @@ def test_degenerate_spheres_around_ray_origins(device, variant):
 
 @pytest.mark.parametrize("variant", [0, 3])
 @pytest.mark.parametrize("kind", ["bit_sets", "lists"])
-def test_spheres_far_from_the_others_are_tested_outside_the_table(device, variant, kind):
+def test_spheres_far_from_the_others_do_not_size_the_tables(device, variant, kind):
     """rt_dirmask.h "Outliers": the headline scene with three far spheres — a big mirror in view that paths bounce off and back into
-    the scene, a tiny one, one overhead —: they are in no set of the table and every served ray tests them directly.  Frames, segment
+    the scene, a tiny one, one overhead —: they do not size the tables and are members of every candidate set instead.  Frames, segment
     counts and hit indices are the oracle's, from two cameras (one of them next to the far mirror: rays that start outside the near box
     scan linearly), RT_OPT_CULL = 2 counts no disagreement with the linear scan, and with RT_OPT_FLAGS bit 5 (the outliers stay in the
     table) the frames are the same."""
