@@ -766,6 +766,31 @@ def test_degenerate_spheres_around_ray_origins(device, variant):
 
 @pytest.mark.parametrize("variant", [0, 3])
 @pytest.mark.parametrize("kind", ["bit_sets", "lists"])
+def test_a_planet_sized_ground_sphere_and_a_sky_dome_are_outliers(device, variant, kind):
+    """The other shape of an outlier: not far away but huge — a ground SPHERE of radius 5 000 under the scene (the paths bounce off it, so
+    rays start on an outlier's surface in the middle of the table) and a dome of radius 3 000 around everything.  |c - median| + r puts
+    both beyond the limit: they do not size the tables and sit in every set.  Frame, segments and hit indices are the oracle's;
+    RT_OPT_CULL = 2 counts no disagreement."""
+    from rsraytracingv3_amd.scene import Geometry, Material, Object
+    scene = cases.headline_scene(5) if kind == "bit_sets" else cases.stress_scene(300, 5)
+    scene.objects = [o for o in scene.objects if o.geometry.kind == 0]  # no plane: the planet is the ground
+    scene.objects.insert(9, Object("planet", Material((0.6, 0.7, 0.5), (0, 0, 0), 0.0, 0.5, 0.3), Geometry.sphere((3.0, -5000.0, -2.0), 5000.0)))
+    scene.objects.insert(30, Object("dome", Material((0.8, 0.8, 1.0), (0.2, 0.3, 1.0), 1.0, 0.5, 1.0), Geometry.sphere((0.0, 0.0, 0.0), 3000.0)))
+    sky, rnd = cases.inputs(128, 64)
+    size, jitter = (192, 108), (0.15, -0.25)
+    ref = run_oracle(scene, size, sky, rnd, jitter, max_objects="live")
+    device.set_option(N.RT_OPT_CULL, 2)
+    try:
+        outs, st = run_gpu(device, scene, size, sky, rnd, jitter, max_objects="live", variant=variant)
+    finally:
+        device.set_option(N.RT_OPT_CULL, 1)
+    assert_frame_equal(outs[0], ref)
+    assert st.last_cull_mismatches == 0 and st.dirmask_cells > 0 and (st.dirmask_lists > 0) == (kind == "lists")
+    assert (ref.hits == 9).any()  # the planet is hit (the dome, seen from inside, never is: ray.hlsl:53-68 takes the near root only)
+
+
+@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("kind", ["bit_sets", "lists"])
 def test_spheres_far_from_the_others_do_not_size_the_tables(device, variant, kind):
     """rt_dirmask.h "Outliers": the headline scene with three far spheres — a big mirror in view that paths bounce off and back into
     the scene, a tiny one, one overhead —: they do not size the tables and are members of every candidate set instead.  Frames, segment
