@@ -93,4 +93,5 @@ if [[ $PART == *b* ]]; then
   cat "$OUT/phases.txt"
   bash tools/dirlist_sweep.sh "$OUT/dirlist_sweep.txt" > /dev/null 2>&1 || true
   python tools/set_scene_time.py 2>&1 | grep -v amdgpu.ids > "$OUT/set_scene_time.txt" || true
+  { python tools/word_boundary_times.py; python tools/outlier_times_large.py; } 2>&1 | grep -v amdgpu.ids > "$OUT/word_boundary_and_outliers.txt" || true
 fi
