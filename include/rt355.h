@@ -119,8 +119,9 @@ RT355_API int rt_has_ab_shapes(void);
 RT355_API int rt_set_skybox(rt_context *ctx, uint32_t width, uint32_t height, const float *rgba32f);
 
 /* `Connection::load_image` + `load_hdri` for the reference's asset format (connection.rs:154-215; `image`
- * 0.25.1 / `exr` 1.72.0 per Cargo.lock): read a single-part scan-line OpenEXR file (compression NONE,
- * RLE, ZIPS, ZIP or PIZ; HALF / FLOAT / UINT channels R, G, B and optionally A) into RGBA32F, alpha 1
+ * 0.25.1 / `exr` 1.72.0 per Cargo.lock): read an OpenEXR file — scan-line or tiled (the full-resolution
+ * level), single- or multi-part (the first part that is not deep and has R, G, B), compression NONE, RLE,
+ * ZIPS, ZIP, PIZ or PXR24; HALF / FLOAT / UINT channels R, G, B and optionally A — into RGBA32F, alpha 1
  * where the file has none, rows top to bottom of the display window.  Host code only (usable without a
  * GPU).  *out_rgba32f is released with rt_exr_free.  Errors: RT_ERR_INVALID_ARGUMENT with the text in
  * rt_exr_last_error() (per thread), worded like the reference's ("Can't find image: ...", "Image

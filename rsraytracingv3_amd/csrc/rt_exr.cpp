@@ -1,4 +1,4 @@
-// rt_exr.cpp — OpenEXR scan-line reader for the skybox (host code, no GPU work).
+// rt_exr.cpp — OpenEXR reader for the skybox (host code, no GPU work).
 //
 // Stands in for `Connection::load_image` (src/gpu/connection.rs:154-162): the reference decodes
 // ./assets/table_mountain_1_8k.exr with the `image` crate 0.25.1 (feature "exr", which wraps the
@@ -8,9 +8,12 @@
 // is exercised against files written by an independent Python writer (tests/exr_writer.py):
 // PARITY UNPINNED — no file produced by another EXR implementation was available to read.
 //
-// Supported: single-part scan-line files, compression NONE / RLE / ZIPS / ZIP / PIZ, channel
-// types HALF / FLOAT / UINT, no subsampling; channels R, G, B (required) and A (optional).
-// Rejected with a message: tiled, multi-part and deep files, PXR24 / B44 / DWA compression.
+// Supported: scan-line and tiled parts (of a tiled part the full-resolution level — ONE_LEVEL, or level (0, 0) of a
+// MIPMAP / RIPMAP file: the reference asks for `largest_resolution_level`), single-part and multi-part files (the first
+// part that is not deep and has R, G and B: the reference's `first_valid_layer`), compression NONE / RLE / ZIPS / ZIP /
+// PIZ / PXR24, channel types HALF / FLOAT / UINT, no subsampling; channels R, G, B (required) and A (optional).
+// Rejected with a message: deep-only files, B44 / B44A (lossy table-driven codecs the `exr` crate reads: not restated
+// here without a file to check against) and DWAA / DWAB (the `exr` crate rejects those too).
 #include <zlib.h>
 
 #include <algorithm>
@@ -384,6 +387,133 @@ bool piz_decode(const uint8_t *in, size_t n_in, const std::vector<Channel> &chan
 
 }  // namespace
 
+namespace {
+
+// One header of the file (a single-part file has one; a multi-part file a list ended by an empty header).
+struct Part {
+  std::vector<Channel> chans;
+  int compression = -1, line_order = 0;
+  int32_t data_win[4] = {0, 0, -1, -1}, disp_win[4] = {0, 0, -1, -1};
+  bool have_data = false, have_disp = false;
+  bool tiled = false, deep = false, have_tiles = false;
+  uint32_t tile_x = 0, tile_y = 0;
+  int level_mode = 0;  // 0 ONE_LEVEL, 1 MIPMAP, 2 RIPMAP: level (0, 0) is the full-resolution image in all three
+  int64_t chunk_count = -1;
+  std::string type;
+  int idx[4] = {-1, -1, -1, -1};  // R G B A
+  bool has_rgb() const { return idx[0] >= 0 && idx[1] >= 0 && idx[2] >= 0; }
+};
+
+// Reads one header's attributes up to its terminating null byte.  `empty` = the header had no attribute at all
+// (the end of a multi-part file's header list).
+int read_header(Reader &r, size_t name_limit, const std::string &bad, Part &part, bool &empty) {
+  empty = true;
+  for (;;) {
+    if (r.p >= r.end) return exr_fail(bad + "truncated header");
+    if (*r.p == 0) {
+      ++r.p;
+      break;
+    }
+    empty = false;
+    const std::string name = r.cstr(name_limit), type = r.cstr(name_limit);
+    const int32_t size = r.get<int32_t>();
+    if (!r.ok || size < 0 || static_cast<size_t>(r.end - r.p) < static_cast<size_t>(size))
+      return exr_fail(bad + "truncated attribute " + name);
+    Reader a{r.p, r.p + size};
+    r.p += size;
+    if (name == "channels" && type == "chlist") {
+      while (a.p < a.end && *a.p != 0) {
+        Channel c;
+        c.name = a.cstr(name_limit);
+        c.type = a.get<int32_t>();
+        (void)a.get<uint32_t>();  // pLinear + 3 reserved bytes
+        const int32_t xs = a.get<int32_t>(), ys = a.get<int32_t>();
+        if (!a.ok) return exr_fail(bad + "truncated channel list");
+        if (c.type < 0 || c.type > 2) return exr_fail(bad + "unknown pixel type of channel " + c.name);
+        if (xs != 1 || ys != 1) return exr_fail(bad + "subsampled channel " + c.name + " is not supported");
+        if (part.chans.size() >= kMaxChannels) return exr_fail(bad + "more than 64 channels");
+        part.chans.push_back(c);
+      }
+    } else if (name == "compression" && type == "compression") {
+      part.compression = a.get<uint8_t>();
+    } else if (name == "dataWindow" && type == "box2i") {
+      for (int32_t &v : part.data_win) v = a.get<int32_t>();
+      part.have_data = a.ok;
+    } else if (name == "displayWindow" && type == "box2i") {
+      for (int32_t &v : part.disp_win) v = a.get<int32_t>();
+      part.have_disp = a.ok;
+    } else if (name == "lineOrder" && type == "lineOrder") {
+      part.line_order = a.get<uint8_t>();
+    } else if (name == "tiles" && type == "tiledesc") {
+      part.tile_x = a.get<uint32_t>();
+      part.tile_y = a.get<uint32_t>();
+      const uint8_t mode = a.get<uint8_t>();
+      if (!a.ok) return exr_fail(bad + "truncated tile description");
+      part.level_mode = mode & 15;
+      part.have_tiles = true;
+    } else if (name == "type" && type == "string") {
+      part.type.assign(reinterpret_cast<const char *>(a.p), static_cast<size_t>(a.end - a.p));
+    } else if (name == "chunkCount" && type == "int") {
+      part.chunk_count = a.get<int32_t>();
+      if (!a.ok || part.chunk_count < 0) return exr_fail(bad + "invalid chunkCount");
+    }
+  }
+  for (size_t i = 0; i < part.chans.size(); ++i) {
+    if (part.chans[i].name == "R") part.idx[0] = static_cast<int>(i);
+    if (part.chans[i].name == "G") part.idx[1] = static_cast<int>(i);
+    if (part.chans[i].name == "B") part.idx[2] = static_cast<int>(i);
+    if (part.chans[i].name == "A") part.idx[3] = static_cast<int>(i);
+  }
+  return RT_OK;
+}
+
+// PXR24: the block's bytes are deflated after a per-line, per-channel split into byte planes (most significant
+// first; a FLOAT keeps its upper 24 bits only) of running differences.  Output: scan-line order like every other
+// decoder here (per line, per channel, `width` native samples).
+bool pxr24_decode(const uint8_t *in, size_t n_in, const std::vector<Channel> &chans, int width, int lines, uint8_t *out,
+                  std::vector<uint8_t> &tmp) {
+  size_t packed_line = 0;
+  for (const Channel &c : chans) packed_line += static_cast<size_t>(width) * (c.type == 1 ? 2 : (c.type == 2 ? 3 : 4));
+  const size_t n_packed = packed_line * static_cast<size_t>(lines);
+  tmp.resize(n_packed);
+  uLongf got = static_cast<uLongf>(n_packed);
+  if (uncompress(tmp.data(), &got, in, static_cast<uLong>(n_in)) != Z_OK || got != n_packed) return false;
+  const uint8_t *p = tmp.data();
+  const size_t n = static_cast<size_t>(width);
+  for (int y = 0; y < lines; ++y) {
+    for (const Channel &c : chans) {
+      uint32_t pixel = 0;
+      if (c.type == 1) {
+        for (size_t x = 0; x < n; ++x) {
+          pixel += static_cast<uint32_t>(p[x]) << 8 | p[n + x];
+          const uint16_t h = static_cast<uint16_t>(pixel);
+          std::memcpy(out + 2 * x, &h, 2);
+        }
+        p += 2 * n;
+        out += 2 * n;
+      } else if (c.type == 2) {
+        for (size_t x = 0; x < n; ++x) {
+          pixel += static_cast<uint32_t>(p[x]) << 24 | static_cast<uint32_t>(p[n + x]) << 16 | static_cast<uint32_t>(p[2 * n + x]) << 8;
+          std::memcpy(out + 4 * x, &pixel, 4);
+        }
+        p += 3 * n;
+        out += 4 * n;
+      } else {
+        for (size_t x = 0; x < n; ++x) {
+          pixel += static_cast<uint32_t>(p[x]) << 24 | static_cast<uint32_t>(p[n + x]) << 16 | static_cast<uint32_t>(p[2 * n + x]) << 8 |
+                   p[3 * n + x];
+          std::memcpy(out + 4 * x, &pixel, 4);
+        }
+        p += 4 * n;
+        out += 4 * n;
+      }
+    }
+  }
+  return true;
+}
+
+}  // namespace
+
 extern "C" {
 
 const char *rt_exr_last_error(void) { return g_error.c_str(); }
@@ -433,90 +563,87 @@ static int exr_read_impl(const char *path, uint32_t *out_width, uint32_t *out_he
   if (r.get<uint32_t>() != 20000630u) return exr_fail(bad + "not an OpenEXR file (magic)");
   const uint32_t version = r.get<uint32_t>();
   if ((version & 0xffu) != 2u) return exr_fail(bad + "unsupported OpenEXR version");
-  if (version & 0x200u) return exr_fail(bad + "tiled files are not supported (scan-line only)");
-  if (version & 0x800u) return exr_fail(bad + "deep data is not supported");
-  if (version & 0x1000u) return exr_fail(bad + "multi-part files are not supported");
+  const bool multipart = (version & 0x1000u) != 0;
+  if ((version & 0x800u) && !multipart) return exr_fail(bad + "deep data is not supported");
   const size_t name_limit = (version & 0x400u) ? 255 : 31;
-  std::vector<Channel> chans;
-  int compression = -1, line_order = 0;
-  int32_t data_win[4] = {0, 0, -1, -1}, disp_win[4] = {0, 0, -1, -1};
-  bool have_data = false, have_disp = false;
+  // Headers.  The reference's reader takes the first layer that has R, G and B and is not deep
+  // (`image` 0.25.1 codecs/openexr.rs: first_valid_layer); so does this one.
+  std::vector<Part> parts;
   for (;;) {
-    if (r.p >= r.end) return exr_fail(bad + "truncated header");
-    if (*r.p == 0) {
-      ++r.p;
-      break;
+    Part part;
+    bool empty = false;
+    const int hrc = read_header(r, name_limit, bad, part, empty);
+    if (hrc != RT_OK) return hrc;
+    if (multipart && empty) break;
+    if (!multipart) {
+      part.tiled = (version & 0x200u) != 0;
+    } else {
+      part.tiled = part.type == "tiledimage";
+      part.deep = part.type == "deepscanline" || part.type == "deeptile";
+      if (!part.tiled && !part.deep && part.type != "scanlineimage") return exr_fail(bad + "part of unknown type '" + part.type + "'");
+      if (part.chunk_count < 0) return exr_fail(bad + "multi-part header without chunkCount");
     }
-    const std::string name = r.cstr(name_limit), type = r.cstr(name_limit);
-    const int32_t size = r.get<int32_t>();
-    if (!r.ok || size < 0 || static_cast<size_t>(r.end - r.p) < static_cast<size_t>(size))
-      return exr_fail(bad + "truncated attribute " + name);
-    Reader a{r.p, r.p + size};
-    r.p += size;
-    if (name == "channels" && type == "chlist") {
-      while (a.p < a.end && *a.p != 0) {
-        Channel c;
-        c.name = a.cstr(name_limit);
-        c.type = a.get<int32_t>();
-        (void)a.get<uint32_t>();  // pLinear + 3 reserved bytes
-        const int32_t xs = a.get<int32_t>(), ys = a.get<int32_t>();
-        if (!a.ok) return exr_fail(bad + "truncated channel list");
-        if (c.type < 0 || c.type > 2) return exr_fail(bad + "unknown pixel type of channel " + c.name);
-        if (xs != 1 || ys != 1) return exr_fail(bad + "subsampled channel " + c.name + " is not supported");
-        if (chans.size() >= kMaxChannels) return exr_fail(bad + "more than 64 channels");
-        chans.push_back(c);
-      }
-    } else if (name == "compression" && type == "compression") {
-      compression = a.get<uint8_t>();
-    } else if (name == "dataWindow" && type == "box2i") {
-      for (int32_t &v : data_win) v = a.get<int32_t>();
-      have_data = a.ok;
-    } else if (name == "displayWindow" && type == "box2i") {
-      for (int32_t &v : disp_win) v = a.get<int32_t>();
-      have_disp = a.ok;
-    } else if (name == "lineOrder" && type == "lineOrder") {
-      line_order = a.get<uint8_t>();
-    }
+    parts.push_back(std::move(part));
+    if (!multipart) break;
+    if (parts.size() > 1024) return exr_fail(bad + "more than 1024 parts");
   }
-  if (chans.empty() || compression < 0 || !have_data || !have_disp) return exr_fail(bad + "required header attribute missing");
+  size_t chosen = parts.size();
+  for (size_t i = 0; i < parts.size() && chosen == parts.size(); ++i)
+    if (!parts[i].deep && parts[i].has_rgb()) chosen = i;
+  if (chosen == parts.size()) {
+    if (!multipart && parts[0].chans.empty()) return exr_fail(bad + "required header attribute missing");
+    return exr_fail(bad + (multipart ? "no part with R, G, B channels" : "no R, G, B channels"));
+  }
+  const Part &part = parts[chosen];
+  const std::vector<Channel> &chans = part.chans;
+  const int compression = part.compression;
+  const int32_t *data_win = part.data_win, *disp_win = part.disp_win;
+  const int *idx = part.idx;
+  if (chans.empty() || compression < 0 || !part.have_data || !part.have_disp || (part.tiled && !part.have_tiles))
+    return exr_fail(bad + "required header attribute missing");
   static const char *kNames[] = {"NONE", "RLE", "ZIPS", "ZIP", "PIZ", "PXR24", "B44", "B44A", "DWAA", "DWAB"};
   int lines_per_block;
   switch (compression) {
     case 0: case 1: case 2: lines_per_block = 1; break;
-    case 3: lines_per_block = 16; break;
+    case 3: case 5: lines_per_block = 16; break;
     case 4: lines_per_block = 32; break;
     default:
       return exr_fail(bad + "compression " + (compression < 10 ? kNames[compression] : "?") + " is not supported "
-                            "(NONE, RLE, ZIPS, ZIP, PIZ are)");
+                            "(NONE, RLE, ZIPS, ZIP, PIZ, PXR24 are)");
   }
-  (void)line_order;  // every chunk carries its own y; the offset table makes the order irrelevant
+  // (lineOrder is not needed: every chunk carries its own coordinates; the offset table makes the order irrelevant)
   const int64_t dw = static_cast<int64_t>(data_win[2]) - data_win[0] + 1, dh = static_cast<int64_t>(data_win[3]) - data_win[1] + 1;
   const int64_t W = static_cast<int64_t>(disp_win[2]) - disp_win[0] + 1, H = static_cast<int64_t>(disp_win[3]) - disp_win[1] + 1;
   if (dw <= 0 || dh <= 0 || W <= 0 || H <= 0 || dw > 65536 || dh > 65536 || W > 65536 || H > 65536)
     return exr_fail(bad + "unreasonable data / display window");
   if (W * H > (1ll << 28) || dw * dh > (1ll << 28))  // 16k x 16k: 4 GiB of RGBA32F — far beyond any skybox
     return exr_fail(bad + "image larger than 2^28 pixels");
-  int idx[4] = {-1, -1, -1, -1};  // R G B A
-  for (size_t i = 0; i < chans.size(); ++i) {
-    if (chans[i].name == "R") idx[0] = static_cast<int>(i);
-    if (chans[i].name == "G") idx[1] = static_cast<int>(i);
-    if (chans[i].name == "B") idx[2] = static_cast<int>(i);
-    if (chans[i].name == "A") idx[3] = static_cast<int>(i);
-  }
-  if (idx[0] < 0 || idx[1] < 0 || idx[2] < 0) return exr_fail(bad + "no R, G, B channels");
-  size_t line_bytes = 0;
-  std::vector<size_t> chan_off;
-  for (const Channel &c : chans) {
-    chan_off.push_back(line_bytes);
-    line_bytes += static_cast<size_t>(dw) * c.bytes();
-  }
+  size_t pixel_bytes = 0;
+  for (const Channel &c : chans) pixel_bytes += static_cast<size_t>(c.bytes());
   // A block's decoded bytes are held twice (raw + tmp): bound them before anything is allocated.  The
   // largest sane block — 64 FLOAT channels would be absurd; 4 FLOAT channels x 65536 px x 32 lines is
   // 32 MiB — is far below this cap.
-  if (line_bytes * static_cast<size_t>(lines_per_block) > kMaxBlockBytes)
-    return exr_fail(bad + "scan-line block larger than 1 GiB");
-  const size_t n_blocks = static_cast<size_t>((dh + lines_per_block - 1) / lines_per_block);
-  if (static_cast<size_t>(r.end - r.p) < n_blocks * 8) return exr_fail(bad + "truncated offset table");
+  int64_t block_w = dw, block_h = lines_per_block, tiles_x = 1, tiles_y = 1;
+  if (part.tiled) {
+    if (part.tile_x == 0 || part.tile_y == 0 || part.tile_x > 65536 || part.tile_y > 65536) return exr_fail(bad + "unreasonable tile size");
+    if (part.level_mode > 2) return exr_fail(bad + "unknown tile level mode");
+    block_w = std::min<int64_t>(part.tile_x, dw);
+    block_h = std::min<int64_t>(part.tile_y, dh);
+    tiles_x = (dw + part.tile_x - 1) / part.tile_x;
+    tiles_y = (dh + part.tile_y - 1) / part.tile_y;
+  }
+  if (pixel_bytes * static_cast<size_t>(block_w) * static_cast<size_t>(block_h) > kMaxBlockBytes)
+    return exr_fail(bad + (part.tiled ? "tile larger than 1 GiB" : "scan-line block larger than 1 GiB"));
+  // Offset tables: one per part, in the parts' order.  Of a tiled part only the full-resolution level is read, whose
+  // tiles come first in its table whatever the level mode.
+  const size_t n_blocks = part.tiled ? static_cast<size_t>(tiles_x * tiles_y) : static_cast<size_t>((dh + lines_per_block - 1) / lines_per_block);
+  for (size_t i = 0; i < chosen; ++i) {
+    const uint64_t skip = static_cast<uint64_t>(parts[i].chunk_count) * 8u;  // multi-part: chunkCount is there (checked above)
+    if (static_cast<uint64_t>(r.end - r.p) < skip) return exr_fail(bad + "truncated offset table");
+    r.p += skip;
+  }
+  if (multipart && static_cast<uint64_t>(part.chunk_count) < n_blocks) return exr_fail(bad + "chunkCount smaller than the image needs");
+  if (static_cast<size_t>(r.end - r.p) / 8 < n_blocks) return exr_fail(bad + "truncated offset table");
   std::vector<uint64_t> offsets(n_blocks);
   std::memcpy(offsets.data(), r.p, n_blocks * 8);
 
@@ -533,12 +660,30 @@ static int exr_read_impl(const char *path, uint32_t *out_width, uint32_t *out_he
     auto fail_block = [&](const char *why) { return exr_fail(bad + why); };
     if (offsets[b] > file.size() || file.size() - offsets[b] < 8) return fail_block("chunk offset outside the file");
     Reader c{file.data() + offsets[b], file.data() + file.size()};
-    const int32_t y0 = c.get<int32_t>();
+    if (multipart && c.get<int32_t>() != static_cast<int32_t>(chosen)) return fail_block("chunk of another part in this part's offset table");
+    int64_t bx0 = 0;  // first column of the block, relative to the data window
+    int32_t y0;       // first line of the block, absolute
+    int64_t width = dw;
+    int lines;
+    if (part.tiled) {
+      const int32_t tx = c.get<int32_t>(), ty = c.get<int32_t>(), lx = c.get<int32_t>(), ly = c.get<int32_t>();
+      if (!c.ok) return fail_block("truncated chunk");
+      if (lx != 0 || ly != 0) return fail_block("tile of a reduced level where a full-resolution tile belongs");
+      if (tx < 0 || ty < 0 || tx >= tiles_x || ty >= tiles_y) return fail_block("chunk with an invalid tile coordinate");
+      bx0 = static_cast<int64_t>(tx) * part.tile_x;
+      width = std::min<int64_t>(part.tile_x, dw - bx0);
+      const int64_t by0 = static_cast<int64_t>(ty) * part.tile_y;
+      y0 = static_cast<int32_t>(data_win[1] + by0);
+      lines = static_cast<int>(std::min<int64_t>(part.tile_y, dh - by0));
+    } else {
+      y0 = c.get<int32_t>();
+      if (y0 < data_win[1] || y0 > data_win[3] || (static_cast<int64_t>(y0) - data_win[1]) % lines_per_block != 0)
+        return fail_block("chunk with an invalid scan-line coordinate");
+      lines = static_cast<int>(std::min<int64_t>(lines_per_block, static_cast<int64_t>(data_win[3]) - y0 + 1));
+    }
     const int32_t n_data = c.get<int32_t>();
-    if (n_data < 0 || static_cast<size_t>(c.end - c.p) < static_cast<size_t>(n_data)) return fail_block("truncated chunk");
-    if (y0 < data_win[1] || y0 > data_win[3] || (static_cast<int64_t>(y0) - data_win[1]) % lines_per_block != 0)
-      return fail_block("chunk with an invalid scan-line coordinate");
-    const int lines = static_cast<int>(std::min<int64_t>(lines_per_block, static_cast<int64_t>(data_win[3]) - y0 + 1));
+    if (!c.ok || n_data < 0 || static_cast<size_t>(c.end - c.p) < static_cast<size_t>(n_data)) return fail_block("truncated chunk");
+    const size_t line_bytes = pixel_bytes * static_cast<size_t>(width);
     const size_t n_raw = line_bytes * static_cast<size_t>(lines);
     raw.resize(n_raw);
     if (static_cast<size_t>(n_data) == n_raw) {
@@ -555,8 +700,19 @@ static int exr_read_impl(const char *path, uint32_t *out_width, uint32_t *out_he
       if (uncompress(tmp.data(), &got, c.p, static_cast<uLong>(n_data)) != Z_OK || got != n_raw)
         return fail_block("corrupt ZIP chunk");
       unpredict_and_interleave(tmp, raw.data());
-    } else if (!piz_decode(c.p, static_cast<size_t>(n_data), chans, static_cast<int>(dw), lines, raw.data())) {
+    } else if (compression == 5) {
+      if (!pxr24_decode(c.p, static_cast<size_t>(n_data), chans, static_cast<int>(width), lines, raw.data(), tmp))
+        return fail_block("corrupt PXR24 chunk");
+    } else if (!piz_decode(c.p, static_cast<size_t>(n_data), chans, static_cast<int>(width), lines, raw.data())) {
       return fail_block("corrupt PIZ chunk");
+    }
+    std::vector<size_t> chan_off;
+    {
+      size_t off = 0;
+      for (const Channel &ch : chans) {
+        chan_off.push_back(off);
+        off += static_cast<size_t>(width) * ch.bytes();
+      }
     }
     for (int l = 0; l < lines; ++l) {
       const int64_t y = static_cast<int64_t>(y0) + l - disp_win[1];  // row in the display window
@@ -565,16 +721,16 @@ static int exr_read_impl(const char *path, uint32_t *out_width, uint32_t *out_he
       for (int k = 0; k < 4; ++k) {
         float *dst = rgba + static_cast<size_t>(y) * W * 4 + k;
         if (idx[k] < 0) {  // no alpha channel: opaque (into_rgba32f)
-          for (int64_t x = 0; x < dw; ++x) {
-            const int64_t X = x + data_win[0] - disp_win[0];
+          for (int64_t x = 0; x < width; ++x) {
+            const int64_t X = bx0 + x + data_win[0] - disp_win[0];
             if (X >= 0 && X < W) dst[X * 4] = 1.0f;
           }
           continue;
         }
         const Channel &ch = chans[idx[k]];
         const uint8_t *src = line + chan_off[idx[k]];
-        for (int64_t x = 0; x < dw; ++x) {
-          const int64_t X = x + data_win[0] - disp_win[0];
+        for (int64_t x = 0; x < width; ++x) {
+          const int64_t X = bx0 + x + data_win[0] - disp_win[0];
           if (X < 0 || X >= W) continue;
           float v;
           if (ch.type == 1) {

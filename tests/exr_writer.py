@@ -1,8 +1,8 @@
-"""A small OpenEXR scan-line WRITER, test infrastructure for the reader in rsraytracingv3_amd/csrc/rt_exr.cpp.
+"""A small OpenEXR WRITER (scan-line, tiled, multi-part), test infrastructure for the reader in rsraytracingv3_amd/csrc/rt_exr.cpp.
 
 Written separately from the reader (Python, encoder side of every step) after the published OpenEXR file
-layout: magic/version, attribute list, chunk offset table, chunks of 1 (NONE, RLE, ZIPS), 16 (ZIP) or 32
-(PIZ) scan lines.  No file made by another EXR implementation exists in this environment, so reader and
+layout: magic/version, attribute list, chunk offset table, chunks of 1 (NONE, RLE, ZIPS), 16 (ZIP, PXR24) or 32
+(PIZ) scan lines, or tiles.  No file made by another EXR implementation exists in this environment, so reader and
 writer pin each other only — "parity unpinned" for real-world files."""
 import heapq
 import struct
@@ -10,8 +10,8 @@ import zlib
 
 import numpy as np
 
-NONE, RLE, ZIPS, ZIP, PIZ = 0, 1, 2, 3, 4
-LINES = {NONE: 1, RLE: 1, ZIPS: 1, ZIP: 16, PIZ: 32}
+NONE, RLE, ZIPS, ZIP, PIZ, PXR24 = 0, 1, 2, 3, 4, 5
+LINES = {NONE: 1, RLE: 1, ZIPS: 1, ZIP: 16, PIZ: 32, PXR24: 16}
 TYPE_CODE = {"uint": 0, "half": 1, "float": 2}
 NP_TYPE = {"uint": np.uint32, "half": np.float16, "float": np.float32}
 
@@ -231,6 +231,37 @@ def _piz(planes, width, lines) -> bytes:
     return head + struct.pack("<i", len(huf)) + huf
 
 
+# ---- PXR24 ------------------------------------------------------------------------------------------
+def float_to_float24(bits):
+    """The upper 24 bits of a float, rounded to nearest (infinities kept, NaNs kept NaN, no rounding into infinity)."""
+    bits = np.asarray(bits, np.uint32).astype(np.int64)
+    s, e, m = bits & 0x80000000, bits & 0x7f800000, bits & 0x007fffff
+    rounded = ((e | m) + (m & 0x80)) >> 8
+    rounded = np.where(rounded >= 0x7f8000, (e | m) >> 8, rounded)
+    nan_m = m >> 8
+    special = np.where(m != 0, (e >> 8) | nan_m | (nan_m == 0), e >> 8)
+    return ((s >> 8) | np.where(e == 0x7f800000, special, rounded)).astype(np.uint32)
+
+
+def _pxr24(planes, width, lines) -> bytes:
+    out = []
+    for y in range(lines):
+        for arr, _ in planes:
+            row = arr[y]
+            if row.dtype == np.float16:
+                v, nbytes = row.view(np.uint16).astype(np.int64), 2
+            elif row.dtype == np.float32:
+                v, nbytes = float_to_float24(row.view(np.uint32)).astype(np.int64), 3
+            else:
+                v, nbytes = row.astype(np.int64), 4
+            d = v.copy()
+            d[1:] = v[1:] - v[:-1]
+            d &= (1 << (8 * nbytes)) - 1
+            for k in range(nbytes - 1, -1, -1):  # most significant plane first
+                out.append(((d >> (8 * k)) & 255).astype(np.uint8).tobytes())
+    return zlib.compress(b"".join(out))
+
+
 # ---- file --------------------------------------------------------------------------------------------
 def _encode_chunk(job):
     """One chunk's payload (module level so that a process pool can run it)."""
@@ -242,16 +273,17 @@ def _encode_chunk(job):
         data = _rle(_predict_and_split(raw))
     elif compression in (ZIPS, ZIP):
         data = zlib.compress(_predict_and_split(raw))
+    elif compression == PXR24:
+        data = _pxr24(planes, w, lines)
     else:
         data = _piz(planes, w, lines)
     return raw if len(data) >= len(raw) else data
 
 
-def write_exr(path, channels, compression=ZIP, display_window=None, data_origin=(0, 0), decreasing_y=False,
-              force_raw_chunks=False, workers=1):
-    """channels: {name: (2-D array, "half" | "float" | "uint")}, all of one shape (the data window).
-    display_window: (xmin, ymin, xmax, ymax), default = the data window placed at data_origin.
-    workers > 1 encodes the chunks in a process pool (the pure-Python PIZ encoder needs it at 8k)."""
+def _build_part(channels, compression=ZIP, display_window=None, data_origin=(0, 0), decreasing_y=False,
+                force_raw_chunks=False, workers=1, tiles=None, mipmap=False, extra_attrs=b""):
+    """-> (attribute bytes without the terminating null, chunks in table order, file order of the chunks).
+    A chunk is its coordinates (y, or tile x, tile y, level x, level y) + payload size + payload."""
     names = sorted(channels)
     h, w = channels[names[0]][0].shape
     x0, y0 = data_origin
@@ -265,8 +297,7 @@ def write_exr(path, channels, compression=ZIP, display_window=None, data_origin=
         chlist += n.encode() + b"\0" + struct.pack("<iB3xii", TYPE_CODE[typ], 0, 1, 1)
         arrays.append((np.ascontiguousarray(arr.astype(NP_TYPE[typ])), 1 if typ == "half" else 2))
     chlist += b"\0"
-    header = struct.pack("<II", 20000630, 2)
-    header += _attr("channels", "chlist", chlist)
+    header = _attr("channels", "chlist", chlist)
     header += _attr("compression", "compression", struct.pack("B", compression))
     header += _attr("dataWindow", "box2i", struct.pack("<4i", *data_win))
     header += _attr("displayWindow", "box2i", struct.pack("<4i", *disp))
@@ -274,27 +305,87 @@ def write_exr(path, channels, compression=ZIP, display_window=None, data_origin=
     header += _attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
     header += _attr("screenWindowCenter", "v2f", struct.pack("<2f", 0.0, 0.0))
     header += _attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
-    header += b"\0"
-    step = LINES[compression]
-    starts = list(range(0, h, step))
-    jobs = ((compression, force_raw_chunks, w, min(r0 + step, h) - r0,
-             [(arr[r0:min(r0 + step, h)], size) for arr, size in arrays]) for r0 in starts)
+    if tiles:
+        header += _attr("tiles", "tiledesc", struct.pack("<IIB", tiles[0], tiles[1], 1 if mipmap else 0))
+    header += extra_attrs
+    jobs, coords = [], []
+    if tiles:
+        tx, ty = tiles
+        levels = [arrays]
+        while mipmap and max(levels[-1][0][0].shape) > 1:  # ROUND_DOWN: each level halves, never below one
+            levels.append([(np.ascontiguousarray(a[::2, ::2][:max(a.shape[0] // 2, 1), :max(a.shape[1] // 2, 1)]), s)
+                           for a, s in levels[-1]])
+        for lv, arrs in enumerate(levels):
+            lh, lw = arrs[0][0].shape
+            for j in range(0, lh, ty):
+                for i in range(0, lw, tx):
+                    tw, th = min(tx, lw - i), min(ty, lh - j)
+                    jobs.append((compression, force_raw_chunks, tw, th,
+                                 [(np.ascontiguousarray(a[j:j + th, i:i + tw]), s) for a, s in arrs]))
+                    coords.append(struct.pack("<4i", i // tx, j // ty, lv, lv))
+    else:
+        step = LINES[compression]
+        for r0 in range(0, h, step):
+            n = min(r0 + step, h) - r0
+            jobs.append((compression, force_raw_chunks, w, n, [(arr[r0:r0 + n], size) for arr, size in arrays]))
+            coords.append(struct.pack("<i", y0 + r0))
     if workers > 1:
         import multiprocessing
         with multiprocessing.get_context("fork").Pool(workers) as pool:
             payloads = pool.map(_encode_chunk, jobs, chunksize=1)
     else:
         payloads = [_encode_chunk(j) for j in jobs]
-    chunks = [struct.pack("<ii", y0 + r0, len(data)) + data for r0, data in zip(starts, payloads)]
+    chunks = [c + struct.pack("<i", len(data)) + data for c, data in zip(coords, payloads)]
+    order = list(range(len(chunks) - 1, -1, -1)) if decreasing_y else list(range(len(chunks)))
+    return header, chunks, order
+
+
+def write_exr(path, channels, compression=ZIP, display_window=None, data_origin=(0, 0), decreasing_y=False,
+              force_raw_chunks=False, workers=1, tiles=None, mipmap=False):
+    """channels: {name: (2-D array, "half" | "float" | "uint")}, all of one shape (the data window).
+    display_window: (xmin, ymin, xmax, ymax), default = the data window placed at data_origin.
+    tiles = (width, height) writes a tiled file; mipmap adds the reduced levels after the full-resolution one.
+    workers > 1 encodes the chunks in a process pool (the pure-Python PIZ encoder needs it at 8k)."""
+    attrs, chunks, order = _build_part(channels, compression, display_window, data_origin, decreasing_y,
+                                       force_raw_chunks, workers, tiles, mipmap)
+    header = struct.pack("<II", 20000630, 2 | (0x200 if tiles else 0)) + attrs + b"\0"
     table_at = len(header)
     offsets, pos = [0] * len(chunks), table_at + 8 * len(chunks)
-    order = range(len(chunks) - 1, -1, -1) if decreasing_y else range(len(chunks))
     body = b""
     for i in order:
         offsets[i] = pos + len(body)
         body += chunks[i]
     with open(path, "wb") as f:
         f.write(header + struct.pack("<%dQ" % len(chunks), *offsets) + body)
+
+
+def write_exr_multipart(path, parts):
+    """parts: list of dicts — the keyword arguments of write_exr (channels, compression, tiles, ...) plus "name" and
+    optionally "type" (default by tiles; "deepscanline" writes a part whose chunks are opaque bytes a reader must skip)."""
+    built = []
+    for k, p in enumerate(parts):
+        p = dict(p)
+        name = p.pop("name", "part%d" % k)
+        typ = p.pop("type", "tiledimage" if p.get("tiles") else "scanlineimage")
+        attrs, chunks, order = _build_part(**p)
+        if typ.startswith("deep"):
+            chunks = [struct.pack("<i", 0) + b"\xde\xad" * 20 for _ in chunks]
+        attrs += _attr("name", "string", name.encode()) + _attr("type", "string", typ.encode())
+        attrs += _attr("chunkCount", "int", struct.pack("<i", len(chunks)))
+        built.append((attrs, chunks, order))
+    deep = any(p.get("type", "").startswith("deep") for p in parts)
+    header = struct.pack("<II", 20000630, 2 | 0x1000 | (0x800 if deep else 0))
+    header += b"".join(attrs + b"\0" for attrs, _, _ in built) + b"\0"
+    pos = len(header) + 8 * sum(len(chunks) for _, chunks, _ in built)
+    tables, body = b"", b""
+    for k, (_, chunks, order) in enumerate(built):
+        offsets = [0] * len(chunks)
+        for i in order:
+            offsets[i] = pos + len(body)
+            body += struct.pack("<i", k) + chunks[i]
+        tables += struct.pack("<%dQ" % len(chunks), *offsets)
+    with open(path, "wb") as f:
+        f.write(header + tables + body)
 
 
 if __name__ == "__main__":
@@ -308,7 +399,7 @@ if __name__ == "__main__":
     if len(sys.argv) < 4 or sys.argv[1] != "skybox":
         raise SystemExit(__doc__)
     width, out_path = int(sys.argv[2]), sys.argv[3]
-    comp = {"piz": PIZ, "zip": ZIP, "zips": ZIPS, "rle": RLE, "none": NONE}[sys.argv[4] if len(sys.argv) > 4 else "piz"]
+    comp = {"piz": PIZ, "zip": ZIP, "zips": ZIPS, "rle": RLE, "none": NONE, "pxr24": PXR24}[sys.argv[4] if len(sys.argv) > 4 else "piz"]
     n_workers = int(sys.argv[5]) if len(sys.argv) > 5 else (os.cpu_count() or 1)
     img = synth.procedural_skybox(width, width // 2)
     write_exr(out_path, {"R": (img[..., 0], "half"), "G": (img[..., 1], "half"), "B": (img[..., 2], "half")}, comp,

@@ -1,6 +1,6 @@
 """The OpenEXR skybox reader (rt_exr_read_rgba32f, Connection.load_image — connection.rs:154-162) against
 files written by tests/exr_writer.py: every supported compression, HALF / FLOAT / UINT channels, both PIZ
-wavelet modes, windows, line orders, raw-stored chunks, alpha handling and the reference's error texts.
+wavelet modes, tiled and multi-part files, windows, line orders, raw-stored chunks, alpha handling and the reference's error texts.
 Host code only — runs without a GPU.  PARITY UNPINNED for files of other EXR writers (none exists here)."""
 import os
 
@@ -122,9 +122,9 @@ def test_error_texts_follow_the_reference(tmp_path):
     X.write_exr(path, {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "half"), "B": (rgb[..., 2], "half")}, X.ZIP)
     data = bytearray(open(path, "rb").read())
     k = data.index(b"compression\0compression\0") + len(b"compression\0compression\0") + 4
-    data[k] = 5  # PXR24
+    data[k] = 6  # B44
     open(path, "wb").write(bytes(data))
-    with pytest.raises(N.RtError, match="PXR24 is not supported"):
+    with pytest.raises(N.RtError, match="B44 is not supported"):
         Connection.load_image(path)
     truncated = bytes(data[:len(data) // 2])
     data[k] = 3
@@ -134,17 +134,130 @@ def test_error_texts_follow_the_reference(tmp_path):
     assert truncated
 
 
+def _float24_expected(rgb):
+    out = np.ones(rgb.shape[:2] + (4,), np.float32)
+    out[..., :3] = (X.float_to_float24(rgb.view(np.uint32)) << 8).astype(np.uint32).view(np.float32)
+    return out
+
+
+@pytest.mark.filterwarnings("ignore:overflow encountered in cast")  # the largest float becomes a half infinity
+@pytest.mark.parametrize("typ", ["half", "float", "uint"])
+def test_pxr24(tmp_path, typ):
+    """PXR24: HALF and UINT come back exactly, a FLOAT with its upper 24 bits (rounded by the writer: the codec is
+    lossy for 32-bit floats by design); 45 rows = a ragged last block of the 16-line blocks; specials survive."""
+    rgb = _image(45, 70, 21)
+    rgb[3, 5] = [np.inf, -np.inf, np.nan]
+    rgb[4, 6] = [3.4028235e38, -0.0, 1e-42]  # the largest float must not round into infinity
+    path = str(tmp_path / "p.exr")
+    if typ == "uint":
+        u = np.random.RandomState(5).randint(0, 2 ** 32, (45, 70, 3), dtype=np.uint64).astype(np.uint32)
+        u[:, :35] = (np.arange(35) * 3)[None, :, None]  # something deflate can shrink, so the chunks are not stored raw
+        X.write_exr(path, {"R": (u[..., 0], typ), "G": (u[..., 1], typ), "B": (u[..., 2], typ)}, X.PXR24)
+        _, got = Connection.load_image(path)
+        assert np.array_equal(got[..., :3], u.astype(np.float32)) and np.all(got[..., 3] == 1.0)
+        return
+    X.write_exr(path, {"R": (rgb[..., 0], typ), "G": (rgb[..., 1], typ), "B": (rgb[..., 2], typ)}, X.PXR24)
+    (w, h), got = Connection.load_image(path)
+    assert (w, h) == (70, 45)
+    want = _expected(rgb, typ) if typ == "half" else _float24_expected(rgb)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if typ == "float":
+        assert np.isnan(got[3, 5, 2]) and got[3, 5, 0] == np.inf and np.isfinite(got[4, 6, 0])
+        assert not np.array_equal(got[..., :3], rgb)  # the case is what it claims to be: 8 bits were dropped
+        mixed = {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "half"),
+                 "A": (rgb[..., 1], "float"), "Z": (rgb[..., 2], "float")}
+        X.write_exr(path, mixed, X.PXR24, decreasing_y=True)
+        _, got = Connection.load_image(path)
+        assert np.array_equal(got[..., 0], rgb[..., 0].astype(np.float16).astype(np.float32))
+        assert np.array_equal(got[..., 1].view(np.uint32), _float24_expected(rgb)[..., 1].view(np.uint32))
+        assert np.array_equal(got[..., 3].view(np.uint32), _float24_expected(rgb)[..., 1].view(np.uint32))
+
+
+@pytest.mark.parametrize("compression", [X.NONE, X.RLE, X.ZIPS, X.ZIP, X.PIZ, X.PXR24])
+def test_tiled_files(tmp_path, compression):
+    """Tiled parts: ragged right and bottom tiles (70 x 45 in tiles of 32 x 16), one tile larger than the image,
+    tiles written bottom-up, and the data window inside / beyond the display window."""
+    rgb = _image(45, 70, 31)
+    chans = {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "half"), "B": (rgb[..., 2], "half")}
+    path = str(tmp_path / "t.exr")
+    X.write_exr(path, chans, compression, tiles=(32, 16), decreasing_y=True)
+    (w, h), got = Connection.load_image(path)
+    assert (w, h) == (70, 45)
+    assert np.array_equal(got.view(np.uint32), _expected(rgb, "half").view(np.uint32))
+    X.write_exr(path, chans, compression, tiles=(128, 64))
+    _, got = Connection.load_image(path)
+    assert np.array_equal(got.view(np.uint32), _expected(rgb, "half").view(np.uint32))
+    X.write_exr(path, chans, compression, tiles=(16, 16), data_origin=(-6, 4), display_window=(0, 0, 59, 59))
+    (w, h), got = Connection.load_image(path)
+    assert (w, h) == (60, 60)
+    want = np.zeros((60, 60, 4), np.float32)
+    want[4:49, 0:60] = _expected(rgb, "half")[:, 6:66]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_tiled_mipmap_reads_the_full_resolution_level(tmp_path):
+    """The reference asks its reader for `largest_resolution_level`: of a MIPMAP file level 0, whose tiles lead the
+    offset table; the reduced levels behind them are never touched."""
+    rgb = _image(37, 53, 32)
+    chans = {"R": (rgb[..., 0], "float"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "float")}
+    path = str(tmp_path / "m.exr")
+    X.write_exr(path, chans, X.ZIP, tiles=(16, 8), mipmap=True)
+    (w, h), got = Connection.load_image(path)
+    assert (w, h) == (53, 37) and np.array_equal(got[..., :3], rgb)
+    # a table whose first entry names a reduced-level tile is refused, not mistaken for pixels
+    data = bytearray(open(path, "rb").read())
+    import struct
+    table = data.index(b"tiledesc\0") + len(b"tiledesc\0") + 4 + 9 + 1
+    n_level0 = 4 * 5
+    offs = list(struct.unpack_from("<%dQ" % (n_level0 + 1), data, table))
+    struct.pack_into("<Q", data, table, offs[n_level0])
+    open(path, "wb").write(bytes(data))
+    with pytest.raises(N.RtError, match="reduced level"):
+        Connection.load_image(path)
+
+
+def test_multipart_files_first_part_with_rgb(tmp_path):
+    """The reference's reader takes `first_valid_layer`: the first part that is not deep and has R, G and B."""
+    rgb, other = _image(20, 30, 41), _image(24, 24, 42)
+    beauty = {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "half"), "B": (rgb[..., 2], "half")}
+    later = {"R": (other[..., 0], "half"), "G": (other[..., 1], "half"), "B": (other[..., 2], "half")}
+    path = str(tmp_path / "mp.exr")
+    X.write_exr_multipart(path, [
+        dict(channels={"Z": (rgb[..., 0], "float")}, compression=X.ZIPS, name="depth"),
+        dict(channels=later, compression=X.ZIPS, name="deep", type="deepscanline"),
+        dict(channels=beauty, compression=X.PIZ, tiles=(16, 16), name="beauty"),
+        dict(channels=later, compression=X.ZIP, name="later")])
+    (w, h), got = Connection.load_image(path)
+    assert (w, h) == (30, 20)
+    assert np.array_equal(got.view(np.uint32), _expected(rgb, "half").view(np.uint32))
+    X.write_exr_multipart(path, [dict(channels=later, compression=X.PXR24, name="only", decreasing_y=True)])
+    (w, h), got = Connection.load_image(path)
+    assert (w, h) == (24, 24) and np.array_equal(got.view(np.uint32), _expected(other, "half").view(np.uint32))
+    X.write_exr_multipart(path, [dict(channels={"Z": (rgb[..., 0], "float")}, compression=X.ZIPS, name="depth"),
+                                 dict(channels=later, compression=X.ZIPS, name="deep", type="deeptile")])
+    with pytest.raises(N.RtError, match="no part with R, G, B"):
+        Connection.load_image(path)
+
+
 def test_corrupted_files_are_rejected_or_read_never_crash(tmp_path):
-    """Byte flips and truncations of valid files (every compression): the reader returns pixels or an error.
+    """Byte flips and truncations of valid files (every compression, tiled with reduced levels, multi-part): the reader returns pixels or an error.
     Runs in a child process so that a memory fault would fail this test instead of killing the test run."""
     import subprocess
     import sys
     rgb = _image(40, 36, 4)
     paths = []
+    chans = {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "half")}
     for comp in (X.NONE, X.RLE, X.ZIPS, X.ZIP, X.PIZ):
         p = str(tmp_path / ("h%d.exr" % comp))
-        X.write_exr(p, {"R": (rgb[..., 0], "half"), "G": (rgb[..., 1], "float"), "B": (rgb[..., 2], "half")}, comp)
+        X.write_exr(p, chans, comp)
         paths.append(p)
+    paths.append(str(tmp_path / "h_pxr24.exr"))
+    X.write_exr(paths[-1], dict(chans, A=(rgb[..., 0].astype(np.uint32), "uint")), X.PXR24)
+    paths.append(str(tmp_path / "h_tiled.exr"))
+    X.write_exr(paths[-1], chans, X.PIZ, tiles=(16, 12), mipmap=True)
+    paths.append(str(tmp_path / "h_parts.exr"))
+    X.write_exr_multipart(paths[-1], [dict(channels={"Z": (rgb[..., 0], "float")}, compression=X.ZIPS, name="depth"),
+                                      dict(channels=chans, compression=X.PXR24, tiles=(20, 20), name="beauty")])
     code = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
@@ -171,7 +284,7 @@ print('survived', done)
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), paths)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "survived 600" in out.stdout
+    assert "survived 960" in out.stdout
 
 
 def _raw_header(channels, data_window, compression):
