@@ -109,9 +109,10 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--tile-chunk", type=int, default=2)
     ap.add_argument("--flags", type=int, default=0)
-    ap.add_argument("--batch-inflight", type=int, default=2,
-                    help="RT_OPT_BATCH_INFLIGHT: multi-frame launches in flight (2 = the library default: the next launch renders "
-                         "while this one's tail drains and resolves; 1 = one at a time: kernel times do not overlap)")
+    ap.add_argument("--batch-inflight", type=int, default=0,
+                    help="RT_OPT_BATCH_INFLIGHT: multi-frame launches in flight (0 = the library's rule: four while their sample buffers "
+                         "fit 2 GiB, the next launches render while this one's tail drains and resolves; 1 = one at a time: kernel "
+                         "times do not overlap)")
     ap.add_argument("--grid-min", type=int, default=0, help="RT_OPT_GRID_MIN: spheres from which a scene gets the sphere grid (0 = library default 129)")
     ap.add_argument("--dirmask", type=int, default=-1, help="RT_OPT_DIRMASK: 0 = secondary rays scan every sphere, 1 = direction-mask table (library default)")
     ap.add_argument("--dirmask-k", type=int, default=0, help="RT_OPT_DIRMASK_K (0 = library default)")
@@ -365,7 +366,7 @@ def main():
     # ---- extra legs: one frame per launch (reference call pattern); 80 zero-padded slots ------------------
     def leg_summary(leg, frames_per_launch):
         blk = leg["block"]
-        return {"frames_per_launch": frames_per_launch, "launches_in_flight": 4 if frames_per_launch == 1 else args.batch_inflight,
+        return {"frames_per_launch": frames_per_launch, "launches_in_flight": int(leg["stats"].last_launches_in_flight),
                 "steps": args.steps, "frames_per_block": blk["frames"],
                 "ms_per_step": round(leg["elapsed"] / args.steps * 1e3, 5),
                 "mrays_per_s": round(leg["total_seg"] / leg["elapsed"] / 1e6, 2),
@@ -462,7 +463,7 @@ def main():
         prof_key.pop("frames_per_launch", None)  # the profile's launches carried 8 frames; traffic is taken per frame
         tuned = (args.variant != -1 or args.dirmask >= 0 or args.dirmask_k or args.dirmask_cells or args.grid_min or args.flags or
                  args.dirlist >= 0 or args.dirlist_min or args.dirlist_k or args.dirlist_cells or args.dirlist_reach or
-                 args.batch_inflight != 2 or args.blocks_per_cu or args.refill_min != 1 or args.tile_chunk != 2 or args.tail_spill >= 0 or args.tail_spill_single >= 0)
+                 args.batch_inflight != 0 or args.blocks_per_cu or args.refill_min != 1 or args.tile_chunk != 2 or args.tail_spill >= 0 or args.tail_spill_single >= 0)
         if prof_key != workload_key or B <= 1 or tuned:  # the profile was collected with the library's defaults
             continue
         if prof.get("kernel_source_sha256") != source_now:
@@ -537,13 +538,13 @@ def main():
             "traffic_source": traffic_source,
             "kernel": kernel_name(head["stats"]),
             "avg_launch_ms": round(blk["kernel_ms"] / launches, 5),
-            "launches_in_flight": args.batch_inflight if B > 1 else 4,
+            "launches_in_flight": int(head["stats"].last_launches_in_flight),
             "kernel_avg_duration_ms": round(blk["kernel_ms_sum"] / launches, 5),
             "timing_note": ("launches overlap (RT_OPT_BATCH_INFLIGHT = %d): avg_launch_ms = HIP-event span from the first kernel's start "
                             "to the last kernel's end of the block / launches (device time counted once); kernel_avg_duration_ms = "
                             "mean HIP-event duration of one kernel, which is what a kernel trace averages and includes the time "
                             "it shared the device with its neighbour; --batch-inflight 1 gives non-overlapping kernels"
-                            % args.batch_inflight) if (B > 1 and args.batch_inflight > 1) else
+                            % int(head["stats"].last_launches_in_flight)) if (B > 1 and int(head["stats"].last_launches_in_flight) > 1) else
                            ("one launch at a time: avg_launch_ms is the mean HIP-event duration of the launch's render step — "
                             "render_blocks followed by tail_stream, which finishes the paths the workgroups hand over (RT_OPT_TAIL_SPILL); "
                             "tail_avg_launch_ms is tail_stream's share of it"

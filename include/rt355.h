@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RT355_ABI_VERSION 4
+#define RT355_ABI_VERSION 5
 #define RT355_API __attribute__((visibility("default")))
 
 typedef enum rt_status {
@@ -89,6 +89,9 @@ typedef struct rt_stats {
   uint32_t spheres_scanned;   /* sphere records the kernels hold: sphere_count minus the records that repeat an earlier one bit for
                                  bit (the zero-filled tail of the reference's 80-slot buffer: 15 -> 1), which can never win
                                  against their first occurrence (ray.hlsl:98-106: strict '<', ascending order)              */
+  uint32_t last_launches_in_flight; /* launches that may overlap on the device the way the last one was issued (RT_OPT_INFLIGHT for
+                                 rt_render, RT_OPT_BATCH_INFLIGHT or the library's rule for rt_render_frames; 1: one at a time)      */
+  uint32_t reserved0;
 } rt_stats;
 
 /* Device-side view of the context's buffers, for zero-copy consumers (RCCL gather,
@@ -397,12 +400,14 @@ enum {
                              * 0: single-frame launches in flight record none that only serve those queries (their kernel times read 0):
                              * a frame then costs the host six HIP calls, 16 us instead of 27 (tools/microbench/host_calls.hip) — what a
                              * render loop that never asks for kernel times wants when a rank's share of a frame is a few microseconds */
-  RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8 (default 2): as RT_OPT_INFLIGHT,
-                              each launch staging its samples in a buffer of its own; the history is updated in frame
-                              order on the context's stream.  2 hides the resolve pass, the tail of a launch and the gap to the
-                              next one behind the next launch's rendering (+4 ... +7 % throughput at 1080p) at the price of a
-                              second staging buffer and of kernel times that overlap (rt_get_launch_span gives the device time);
-                              1 = one launch at a time.                                                                 */
+  RT_OPT_BATCH_INFLIGHT = 8 /* multi-frame launches (rt_render_frames) in flight at once, 1..8, or 0 (default) = the library's
+                              rule: four while the launches' sample buffers fit 2 GiB together, else down to two
+                              (rt_stats.last_launches_in_flight says what a launch got).  As RT_OPT_INFLIGHT, each launch
+                              stages its samples in a buffer of its own; the history is updated in frame order on the
+                              context's stream.  Launches in flight hide the resolve pass, the tail of a launch and the gap to
+                              the next one behind the next launches' rendering (1 -> 2: +4 ... +8 % throughput at 1080p, 2 -> 4:
+                              +1 ... +5 %) at the price of the staging buffers and of kernel times that overlap
+                              (rt_get_launch_span gives the device time); 1 = one launch at a time.                          */
 };
 RT355_API int rt_set_option(rt_context *ctx, int option, int value);
 RT355_API int rt_set_variant(rt_context *ctx, int variant); /* = rt_set_option(RT_OPT_VARIANT) */

@@ -44,7 +44,8 @@ class RtStats(C.Structure):
                 ("last_resolve_ms", C.c_float), ("last_variant", C.c_uint32), ("last_stage", C.c_uint32),
                 ("grid_cells", C.c_uint32), ("grid_items", C.c_uint32),
                 ("dirmask_cells", C.c_uint32), ("dirmask_bins", C.c_uint32), ("tail_spill_unavailable", C.c_uint32),
-                ("path_queue_bytes", C.c_uint64), ("dirmask_lists", C.c_uint32), ("spheres_scanned", C.c_uint32)]
+                ("path_queue_bytes", C.c_uint64), ("dirmask_lists", C.c_uint32), ("spheres_scanned", C.c_uint32),
+                ("last_launches_in_flight", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class RtGridInfo(C.Structure):

@@ -83,7 +83,9 @@ constexpr int kDefaultDirlistReach = 32;       // RT_OPT_DIRLIST_REACH: the larg
 constexpr int kDefaultTailSpillLists = 24;     // RT_OPT_TAIL_SPILL of scenes with candidate lists (one-wave workgroups: 16 / 24 / 32: 37.7 / 37.8 / 37.4)
 constexpr int kDefaultGridMinSpheres = 129;    // RT_OPT_GRID_MIN
 constexpr int kDefaultInflight = 4;            // RT_OPT_INFLIGHT
-constexpr int kDefaultBatchInflight = 2;       // RT_OPT_BATCH_INFLIGHT: the next multi-frame launch renders while this one's tail drains and resolves
+constexpr int kDefaultBatchInflight = 4;       // RT_OPT_BATCH_INFLIGHT = 0 (the library's rule): the next multi-frame launches render while this one's tail drains and
+                                               // resolves; four while their sample buffers fit kBatchLanesBudget, else down to two
+constexpr uint64_t kBatchLanesBudget = 2ull << 30;  // bytes of sample buffers the lanes of multi-frame launches may hold together under that rule
                                                // (round 3: 53.9 -> 57.8 Grays/s on the headline; one at a time: kernel times that do not overlap)
 constexpr int kDefaultTailSpillSingle = 32;    // RT_OPT_TAIL_SPILL_SINGLE: single frames in flight of at least kTailMinTilesSingle tiles spill too.  Round 3 measured
                                                // it in runs of 20 frames between two synchronisations (-4 %: tail_stream's fixed ~35 us per launch) and left it
@@ -217,8 +219,11 @@ constexpr uint32_t kTailMinBouncesSingle = 7;    // ... and of at least this ref
 constexpr uint32_t kTailMinBouncesSingleLists = 5;  // ... on a scene with candidate lists (1 024 spheres, spill off / on at 3 / 4 / 5 / 8 bounces: 38.5 / 35.1, 36.1 / 34.6,
                                                     // 33.1 / 34.0, 26.9 / 33.2; staged scenes at 6 / 7: 50.5 / 50.4, 48.8 / 49.5)
 constexpr uint64_t kTailMinTilesSingle = 24000;  // ... of a single-frame launch in flight (a whole 1080p frame is 32 400; a rank's share of one is not worth it)
-constexpr uint64_t kTailMinTiles = 100000;       // 8x8 tiles from which a launch spills (1080p: 2 frames per launch 42.8 Grays/s without /
-                                                 // 41.0 with the spill, 4 frames 47.6 / 48.7, 8 frames 50.2 / 52.2: from three frames up)
+constexpr uint64_t kTailMinTiles = 90000;        // 8x8 tiles from which a multi-frame launch spills: three 1080p frames (97 200).  Round 3, one launch at a time: 2 frames
+                                                 // per launch 42.8 Grays/s without / 41.0 with the spill, 4 frames 47.6 / 48.7, 8 frames 50.2 / 52.2.  With launches in flight
+                                                 // (tools/small_batch_times.py, two / four in flight): 2 frames 45.0 / 46.9 and 49.1 / 48.4, 3 frames 44.9 / 49.1 and 50.7 / 50.8
+constexpr uint64_t kTailMinTilesLists = 48000;   // ... on a scene with candidate lists, whose tails are longer: from two 1080p frames (2 frames 27.7 / 36.3 and 28.0 / 39.1 Grays/s,
+                                                 // 3 frames 28.4 / 38.0 and 28.8 / 40.9; a single frame in flight: kTailMinTilesSingle)
 uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const LaunchConfig &lc, uint32_t wanted, uint32_t *shard_cap);
 int tail_blocks_per_cu(size_t lds_bytes, bool lists);
 int launch_sqrt_exhaustive(unsigned long long *d_mismatches, hipStream_t stream);

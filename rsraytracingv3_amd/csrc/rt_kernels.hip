@@ -2873,7 +2873,7 @@ uint32_t tail_spill_plan(const DeviceScene &sc, const FrameParams &fp, const Lau
   if (wanted == 0u || !sample_only(fp) || !sc.dm.enabled || pick_variant(sc, fp, lc) != 3) return 0u;
   // nothing to hand over when the first shading is the last; and tail_stream costs a launch ~35 us whatever it holds, which
   // small launches do not earn back (RT_OPT_FLAGS bit 2 lifts the size rule: tests)
-  const uint64_t min_tiles = fp.batch > 1u ? kTailMinTiles : kTailMinTilesSingle;
+  const uint64_t min_tiles = fp.batch > 1u ? ((sc.dm.enabled && sc.dm.lists) ? kTailMinTilesLists : kTailMinTiles) : kTailMinTilesSingle;
   if (fp.batch == 1u && !(lc.flags & 4) && fp.reflection_limit < ((sc.dm.enabled && sc.dm.lists) ? kTailMinBouncesSingleLists : kTailMinBouncesSingle))
     return 0u;
   if (fp.reflection_limit < 2u || (launch_tiles(fp) < min_tiles && !(lc.flags & 4))) return 0u;

@@ -137,7 +137,7 @@ struct rt_context {
   uint32_t occupancy_records = ~0u;  // ... a scene image of this many records
   static constexpr int kMaxInflight = 8;
   int inflight = kDefaultInflight;
-  int batch_inflight = kDefaultBatchInflight;  // RT_OPT_BATCH_INFLIGHT
+  int batch_inflight = 0;  // RT_OPT_BATCH_INFLIGHT; 0 = the library's rule (batch_lanes below)
   uint64_t prep_generation = 0;                 // bumped whenever prep_done is re-recorded
   uint64_t prep_seen[kMaxInflight] = {};        // generation each render stream has already waited for
   // direction masks (rt_dirmask.h): table of candidate-sphere sets for the secondary rays of scenes with up to 64 spheres
@@ -1185,8 +1185,8 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       ctx->tail_spill_single = value;
       return RT_OK;
     case RT_OPT_BATCH_INFLIGHT:
-      if (value < 1 || value > rt_context::kMaxInflight)
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BATCH_INFLIGHT takes 1..%d", rt_context::kMaxInflight);
+      if (value < 0 || value > rt_context::kMaxInflight)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_BATCH_INFLIGHT takes 0..%d", rt_context::kMaxInflight);
       ctx->batch_inflight = value;
       return RT_OK;
     default:
@@ -1347,7 +1347,16 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   // Single frames keep two launches in flight (see rt_context::inflight) unless a per-frame diagnostic output
   // (segments, hits) is on: those buffers describe ONE frame and two kernels must not write them at once.
   // Multi-frame launches overlap the same way when RT_OPT_BATCH_INFLIGHT >= 2 (each lane then stages a whole batch).
-  const int lanes = batch == 1u ? ctx->inflight : ctx->batch_inflight;
+  // Multi-frame launches in flight when the host left the choice to the library: four (8 frames of 1080p per launch, 2 -> 4 in flight:
+  // headline +0.7 %, the reference's 80 slots +1.8 %, 1 024 spheres +1.4 %; 4 frames per launch +5 %; tools/small_batch_times.py) while
+  // the lanes' sample buffers stay within kBatchLanesBudget together, never fewer than two (8 frames of 3840x2160 are 0.8 GB a lane: two).
+  int batch_lanes = ctx->batch_inflight;
+  if (batch > 1u && batch_lanes == 0) {
+    const uint64_t lane_bytes = static_cast<uint64_t>((ctx->local_rows + 7u) / 8u * 8u) * ctx->width * batch * 3u * sizeof(float);
+    const uint64_t fit = kBatchLanesBudget / (lane_bytes ? lane_bytes : 1u);
+    batch_lanes = fit >= static_cast<uint64_t>(kDefaultBatchInflight) ? kDefaultBatchInflight : (fit < 2u ? 2 : static_cast<int>(fit));
+  }
+  const int lanes = batch == 1u ? ctx->inflight : batch_lanes;
   const bool pipelined = lanes >= 2 && !(ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS));
   const int lane = static_cast<int>(ctx->pipe_frames % static_cast<uint64_t>(lanes < 1 ? 1 : lanes));
   const int stream_index = lane;
@@ -1595,6 +1604,7 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
   ctx->timing_valid = true;
   ctx->stats.frames += 1;
   ctx->stats.last_batch = batch;
+  ctx->stats.last_launches_in_flight = pipelined ? static_cast<uint32_t>(lanes) : 1u;
   return RT_OK;
 }
 

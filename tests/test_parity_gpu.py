@@ -635,7 +635,8 @@ def test_intermediate_frames_of_a_batch_launch(device, accum):
 
 @pytest.mark.parametrize("accum", [N.RT_ACCUM_SRGB8, N.RT_ACCUM_FLOAT32])
 def test_multi_frame_launches_in_flight_equal_one_at_a_time(device, accum):
-    """RT_OPT_BATCH_INFLIGHT (default 2; here 3, 2 and 1) with RT_OPT_INFLIGHT 4 / 2 / 1: a mixed sequence of multi-frame
+    """RT_OPT_BATCH_INFLIGHT (default 0 = the library's rule, four for launches this small; here also 3, 2 and 1) with
+    RT_OPT_INFLIGHT 4 / 4 / 2 / 1: a mixed sequence of multi-frame
     launches and single frames, queued without a sync, the random texture replaced on the device in between — launches
     overlap on the internal streams, the history is folded strictly in frame order, so texels and floats equal those of
     one launch at a time.  rt_get_launch_span: the device time of overlapping launches is less than the sum of their
@@ -648,7 +649,7 @@ def test_multi_frame_launches_in_flight_equal_one_at_a_time(device, accum):
     jit = synth.jitter_sequence(11, total)
     results = {}
     try:
-        for lanes_batch, lanes_single in ((3, 4), (2, 2), (1, 1)):
+        for lanes_batch, lanes_single in ((0, 4), (3, 4), (2, 2), (1, 1)):
             device.set_partition(0, 1, 8)
             device.set_accum_mode(accum)
             device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
@@ -673,6 +674,7 @@ def test_multi_frame_launches_in_flight_equal_one_at_a_time(device, accum):
                     conn.draw_frames([(float(x), float(y)) for x, y in jit[k:k + frames]], k)
                 k += frames
             device.sync()
+            assert device.stats().last_launches_in_flight == (lanes_batch or 4)  # the last launch carried 4 frames
             n_launches = len(sequence)
             kms = np.zeros(n_launches, np.float32)
             device.call("rt_get_frame_history", n_launches, None, None, kms.ctypes.data_as(C.c_void_p))
@@ -685,7 +687,7 @@ def test_multi_frame_launches_in_flight_equal_one_at_a_time(device, accum):
     finally:
         device.set_option(N.RT_OPT_BATCH_INFLIGHT, 1)
         device.set_option(N.RT_OPT_INFLIGHT, 4)
-    for lanes in (3, 2):
+    for lanes in (0, 3, 2):
         assert np.array_equal(results[lanes][0].view(np.uint32), results[1][0].view(np.uint32))
         assert np.array_equal(results[lanes][1], results[1][1])
     with pytest.raises(N.RtError):
