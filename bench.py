@@ -113,6 +113,7 @@ def main():
                     help="RT_OPT_BATCH_INFLIGHT: multi-frame launches in flight (0 = the library's rule: four while their sample buffers "
                          "fit 2 GiB, the next launches render while this one's tail drains and resolves; 1 = one at a time: kernel "
                          "times do not overlap)")
+    ap.add_argument("--inflight", type=int, default=0, help="RT_OPT_INFLIGHT: single-frame launches in flight (0 = library default)")
     ap.add_argument("--grid-min", type=int, default=0, help="RT_OPT_GRID_MIN: spheres from which a scene gets the sphere grid (0 = library default 129)")
     ap.add_argument("--dirmask", type=int, default=-1, help="RT_OPT_DIRMASK: 0 = secondary rays scan every sphere, 1 = direction-mask table (library default)")
     ap.add_argument("--dirmask-k", type=int, default=0, help="RT_OPT_DIRMASK_K (0 = library default)")
@@ -187,6 +188,8 @@ def main():
     dev.set_option(N.RT_OPT_TILE_CHUNK, args.tile_chunk)
     dev.set_option(N.RT_OPT_FLAGS, args.flags)
     dev.set_option(N.RT_OPT_BATCH_INFLIGHT, args.batch_inflight)
+    if args.inflight > 0:
+        dev.set_option(N.RT_OPT_INFLIGHT, args.inflight)
     if args.grid_min > 0:
         dev.set_option(N.RT_OPT_GRID_MIN, args.grid_min)
     if args.dirmask >= 0:

@@ -357,10 +357,12 @@ enum {
                               host time from device time (tools/multi_times.py); the frames are garbage                         */
   RT_OPT_CULL = 5,         /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
                               scan is re-done in full and disagreements are counted in rt_stats     */
-  RT_OPT_INFLIGHT = 6,     /* single-frame launches (rt_render / rt_render_frame) in flight at once, 1..8 (default 4):
+  RT_OPT_INFLIGHT = 6,     /* single-frame launches (rt_render / rt_render_frame) in flight at once, 1..8, or 0 (default) = the library's rule: four,
+                              five for paths of one or two segments (reflection_limit <= 2: +9 % / +2 %):
                               frame k + 1 starts rendering on another internal stream while the last
-                              workgroups of frame k drain (a whole 1080p frame gains nothing beyond 2; the small
-                              launches of a rank's strips of a tile-split frame gain up to 4) — the reference's loop issues one frame per turn
+                              workgroups of frame k drain (3 and 6 are slower than 2 and 5: the runtime deals streams to four
+                              hardware queues in turn; the environment variable RT355_STREAM_PAD=k, a diagnostic, makes rt_create
+                              create k idle streams first and so rotates that deal) — the reference's loop issues one frame per turn
                               (app.rs:208-254) and one 1080p frame leaves a fifth of the GPU idle during its
                               ramp-up and tail; the history is still updated strictly in frame order on the
                               context's stream.  1 = one launch at a time (kernel times do not overlap).     */

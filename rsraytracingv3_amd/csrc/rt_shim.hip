@@ -136,7 +136,7 @@ struct rt_context {
   int occupancy_blocks = 0;          // cached hipOccupancyMaxActiveBlocksPerMultiprocessor answer for ...
   uint32_t occupancy_records = ~0u;  // ... a scene image of this many records
   static constexpr int kMaxInflight = 8;
-  int inflight = kDefaultInflight;
+  int inflight = 0;  // RT_OPT_INFLIGHT; 0 = the library's rule (single_lanes in render_frames)
   int batch_inflight = 0;  // RT_OPT_BATCH_INFLIGHT; 0 = the library's rule (batch_lanes below)
   uint64_t prep_generation = 0;                 // bumped whenever prep_done is re-recorded
   uint64_t prep_seen[kMaxInflight] = {};        // generation each render stream has already waited for
@@ -551,6 +551,12 @@ int rt_create(int device_id, rt_context **out_ctx) {
       return bail(RT_ERR_DEVICE);
   for (int i = 0; i < 2; ++i)
     if (hipEventCreateWithFlags(&ctx->rnd_last_use[i], hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
+  if (const char *pad = std::getenv("RT355_STREAM_PAD")) {  // experiment: shift the render streams' places in the runtime's round-robin over its hardware queues
+    for (int i = 0; i < std::atoi(pad) && i < 8; ++i) {
+      hipStream_t dummy;
+      if (hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking) != hipSuccess) return bail(RT_ERR_DEVICE);
+    }
+  }
   for (int i = 0; i < rt_context::kMaxInflight; ++i)
     if (hipStreamCreateWithFlags(&ctx->render_stream[i], hipStreamNonBlocking) != hipSuccess) return bail(RT_ERR_DEVICE);
   if (hipEventCreateWithFlags(&ctx->prep_done, hipEventDisableTiming) != hipSuccess) return bail(RT_ERR_DEVICE);
@@ -1137,8 +1143,8 @@ int rt_set_option(rt_context *ctx, int option, int value) {
       ctx->grid_min_spheres = value < 1 ? 1 : value;
       return RT_OK;
     case RT_OPT_INFLIGHT:
-      if (value < 1 || value > rt_context::kMaxInflight)
-        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_INFLIGHT takes 1..%d", rt_context::kMaxInflight);
+      if (value < 0 || value > rt_context::kMaxInflight)
+        return fail(ctx, RT_ERR_INVALID_ARGUMENT, "RT_OPT_INFLIGHT takes 0..%d", rt_context::kMaxInflight);
       ctx->inflight = value;  // a frame already in flight keeps its lane: lanes are only re-used after their resolve
       return RT_OK;
     case RT_OPT_DIRMASK:
@@ -1356,7 +1362,11 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     const uint64_t fit = kBatchLanesBudget / (lane_bytes ? lane_bytes : 1u);
     batch_lanes = fit >= static_cast<uint64_t>(kDefaultBatchInflight) ? kDefaultBatchInflight : (fit < 2u ? 2 : static_cast<int>(fit));
   }
-  const int lanes = batch == 1u ? ctx->inflight : batch_lanes;
+  // Single frames in flight when the host left the choice to the library: kDefaultInflight (four), five for paths of one or two segments
+  // (tools/inflight_by_bounces.py, 1080p, 4 / 5 in flight: one bounce 0.0489 / 0.0449 ms per frame, two 0.0688 / 0.0676, three to six level,
+  // eight and more 0.1162 / 0.1146 .. 0.1178 — five is bimodal there, and cost bench.py's one-frame leg 4 % in one run of three).
+  const int single_lanes = ctx->inflight != 0 ? ctx->inflight : (ctx->config.reflection_limit <= 2u ? kDefaultInflight + 1 : kDefaultInflight);
+  const int lanes = batch == 1u ? single_lanes : batch_lanes;
   const bool pipelined = lanes >= 2 && !(ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS));
   const int lane = static_cast<int>(ctx->pipe_frames % static_cast<uint64_t>(lanes < 1 ? 1 : lanes));
   const int stream_index = lane;

@@ -492,7 +492,7 @@ def test_streamed_shape_under_a_partition_and_its_fall_back(device):
         assert st1.last_variant == 3
         assert_frame_equal(outs[0], run_oracle(scene, (96, 64), sky, rnd, (0.0, 0.0)))
     finally:
-        device.set_option(N.RT_OPT_INFLIGHT, 4)
+        device.set_option(N.RT_OPT_INFLIGHT, 0)
         device.set_partition(0, 1, 8)
 
 
@@ -552,7 +552,7 @@ def test_two_frames_in_flight_equal_one_at_a_time_and_the_oracle(device, accum):
     sky, _ = cases.inputs(256, 128)
     jit = synth.jitter_sequence(9, 12)
     results = {}
-    for inflight in (4, 2, 1):
+    for inflight in (0, 5, 4, 2, 1):  # 0 = the library's rule: four, five for paths of one or two segments
         device.set_partition(0, 1, 8)
         device.set_accum_mode(accum)
         device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
@@ -571,8 +571,17 @@ def test_two_frames_in_flight_equal_one_at_a_time_and_the_oracle(device, accum):
             conn.frame_data.progressive_count = k
             conn.draw()
         device.sync()
+        assert device.stats().last_launches_in_flight == (inflight or 4)
         results[inflight] = (target.read_rgbf32(), target.read_rgba8())
-    device.set_option(N.RT_OPT_INFLIGHT, 4)
+    device.set_option(N.RT_OPT_INFLIGHT, 0)
+    short = cases.headline_scene(2)
+    conn = Connection(short, device, sky, rt, max_objects="live")
+    conn.update_buffers(size, short, (0.0, 0.0))
+    conn.draw()
+    device.sync()
+    assert device.stats().last_launches_in_flight == 5
+    assert np.array_equal(results[0][0].view(np.uint32), results[1][0].view(np.uint32)) and np.array_equal(results[0][1], results[1][1])
+    assert np.array_equal(results[5][0].view(np.uint32), results[1][0].view(np.uint32)) and np.array_equal(results[5][1], results[1][1])
     assert np.array_equal(results[4][0].view(np.uint32), results[1][0].view(np.uint32)) and np.array_equal(results[4][1], results[1][1])
     assert np.array_equal(results[2][0].view(np.uint32), results[1][0].view(np.uint32))
     assert np.array_equal(results[2][1], results[1][1])
@@ -686,7 +695,7 @@ def test_multi_frame_launches_in_flight_equal_one_at_a_time(device, accum):
             results[lanes_batch] = (target.read_rgbf32(), target.read_rgba8())
     finally:
         device.set_option(N.RT_OPT_BATCH_INFLIGHT, 1)
-        device.set_option(N.RT_OPT_INFLIGHT, 4)
+        device.set_option(N.RT_OPT_INFLIGHT, 0)
     for lanes in (0, 3, 2):
         assert np.array_equal(results[lanes][0].view(np.uint32), results[1][0].view(np.uint32))
         assert np.array_equal(results[lanes][1], results[1][1])

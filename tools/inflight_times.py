@@ -23,7 +23,7 @@ scene = cases.headline_scene(8)
 for size in ((1920, 1080), (3840, 2160)):
     for world in (1, 2, 4, 8):
         row = []
-        for k in (1, 2, 4, 8):
+        for k in (1, 2, 4, 5, 8):
             dev.set_option(N.RT_OPT_INFLIGHT, k)
             dev.set_partition(0, world, 8)
             RenderTarget.new(dev, size)
@@ -41,6 +41,6 @@ for size in ((1920, 1080), (3840, 2160)):
                 best = min(best, (time.perf_counter() - t0) / 256)
             row.append("%d in flight: %.4f ms" % (k, best * 1e3))
         print("%dx%d  N=%d   %s" % (size[0], size[1], world, "   ".join(row)), flush=True)
-dev.set_option(N.RT_OPT_INFLIGHT, 4)
+dev.set_option(N.RT_OPT_INFLIGHT, 0)
 dev.set_partition(0, 1, 8)
 dev.close()
