@@ -358,7 +358,8 @@ enum {
   RT_OPT_CULL = 5,         /* primary-ray tile culling: 0 off, 1 on (default), 2 on + every culled
                               scan is re-done in full and disagreements are counted in rt_stats     */
   RT_OPT_INFLIGHT = 6,     /* single-frame launches (rt_render / rt_render_frame) in flight at once, 1..8, or 0 (default) = the library's rule: four,
-                              five for paths of one or two segments (reflection_limit <= 2: +9 % / +2 %):
+                              five for short launches (reflection_limit <= 2: +9 % / +2 %; a rank's share of a tile-split frame,
+                              i.e. fewer 8x8 tiles than a 1080p frame has: +5 ... +19 %):
                               frame k + 1 starts rendering on another internal stream while the last
                               workgroups of frame k drain (3 and 6 are slower than 2 and 5: the runtime deals streams to four
                               hardware queues in turn; the environment variable RT355_STREAM_PAD=k, a diagnostic, makes rt_create

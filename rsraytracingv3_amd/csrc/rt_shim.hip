@@ -1362,10 +1362,14 @@ static int render_frames(rt_context *ctx, uint32_t batch, const float *jitter, c
     const uint64_t fit = kBatchLanesBudget / (lane_bytes ? lane_bytes : 1u);
     batch_lanes = fit >= static_cast<uint64_t>(kDefaultBatchInflight) ? kDefaultBatchInflight : (fit < 2u ? 2 : static_cast<int>(fit));
   }
-  // Single frames in flight when the host left the choice to the library: kDefaultInflight (four), five for paths of one or two segments
+  // Single frames in flight when the host left the choice to the library: kDefaultInflight (four), five for short launches — paths of one or two segments
   // (tools/inflight_by_bounces.py, 1080p, 4 / 5 in flight: one bounce 0.0489 / 0.0449 ms per frame, two 0.0688 / 0.0676, three to six level,
   // eight and more 0.1162 / 0.1146 .. 0.1178 — five is bimodal there, and cost bench.py's one-frame leg 4 % in one run of three).
-  const int single_lanes = ctx->inflight != 0 ? ctx->inflight : (ctx->config.reflection_limit <= 2u ? kDefaultInflight + 1 : kDefaultInflight);
+  // A rank's share of a tile-split frame (fewer tiles than a whole 1080p frame: the launches that do not spill either) gains the same way
+  // (tools/inflight_times.py, 4 / 5 in flight: 1080p N = 2 / 4 / 8 0.0651 / 0.0637, 0.0380 / 0.0352, 0.0287 / 0.0242 ms; 3840x2160 N = 8 0.0625 / 0.0592).
+  const uint64_t single_tiles = static_cast<uint64_t>((ctx->width + 7u) / 8u) * ((ctx->local_rows + 7u) / 8u);
+  const bool short_launch = ctx->config.reflection_limit <= 2u || single_tiles < kTailMinTilesSingle;
+  const int single_lanes = ctx->inflight != 0 ? ctx->inflight : (short_launch ? kDefaultInflight + 1 : kDefaultInflight);
   const int lanes = batch == 1u ? single_lanes : batch_lanes;
   const bool pipelined = lanes >= 2 && !(ctx->out_flags & (RT_OUT_SEGMENTS | RT_OUT_HITS));
   const int lane = static_cast<int>(ctx->pipe_frames % static_cast<uint64_t>(lanes < 1 ? 1 : lanes));

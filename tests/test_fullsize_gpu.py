@@ -71,8 +71,10 @@ def test_1080p_headline_frame_equals_oracle(device):
 def test_kernel_shapes_agree_and_are_deterministic(device, size):
     scene = cases.headline_scene(8)
     sums, segs = [], []
+    device.set_option(N.RT_OPT_INFLIGHT, 0)  # the library's rule: a whole frame of 8 bounces renders four in flight (short launches: five)
     for variant in (-1, 0, 1, 2, 3, 3):   # the repeated one checks run-to-run determinism
         target, st = render(device, scene, size, (-0.2, 0.4), variant=variant)
+        assert st.last_launches_in_flight == 4
         sums.append(crc(target.read_rgba8()))
         segs.append(st.last_segments)
     assert len(set(sums)) == 1 and len(set(segs)) == 1

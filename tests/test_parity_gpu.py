@@ -552,7 +552,7 @@ def test_two_frames_in_flight_equal_one_at_a_time_and_the_oracle(device, accum):
     sky, _ = cases.inputs(256, 128)
     jit = synth.jitter_sequence(9, 12)
     results = {}
-    for inflight in (0, 5, 4, 2, 1):  # 0 = the library's rule: four, five for paths of one or two segments
+    for inflight in (0, 5, 4, 2, 1):  # 0 = the library's rule: four, five for short launches (paths of one or two segments, or fewer tiles than a 1080p frame: this one)
         device.set_partition(0, 1, 8)
         device.set_accum_mode(accum)
         device.set_outputs(N.RT_OUT_RGBA8 | N.RT_OUT_RGBF32)
@@ -571,7 +571,7 @@ def test_two_frames_in_flight_equal_one_at_a_time_and_the_oracle(device, accum):
             conn.frame_data.progressive_count = k
             conn.draw()
         device.sync()
-        assert device.stats().last_launches_in_flight == (inflight or 4)
+        assert device.stats().last_launches_in_flight == (inflight or 5)
         results[inflight] = (target.read_rgbf32(), target.read_rgba8())
     device.set_option(N.RT_OPT_INFLIGHT, 0)
     short = cases.headline_scene(2)
